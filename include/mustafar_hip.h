@@ -1,0 +1,96 @@
+/*
+ * mustafar_hip.h -- C ABI of libmustafar_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary of the Mustafar sparse-attention decode path.  Every entry point is
+ * `extern "C"`, takes plain device pointers / sizes and a `hipStream_t` passed as `void*`,
+ * launches asynchronously on that stream and returns a hipError_t value as `int`
+ * (0 == hipSuccess; MUSTAFAR_EINVAL for arguments the kernels do not support).
+ * No torch types cross this boundary.  Citations are relative to the reference tree.
+ *
+ * Compressed-cache format (kernel/compression.py:8-247, consumed by kernel/csrc/SpMM_Kernel.cuh):
+ *   bmp        u64 [B', tiles]       bit (63-i) set <=> element i of the 64-element tile != 0
+ *   idx        u32 [B', tiles+1]     exclusive prefix of ceil8(nnz)/2 per tile (half2 units)
+ *   NZ         fp16 stream           per tile ceil8(nnz) halfs: non-zeros in element order, then 0 padding
+ *   NZ_offset  u32 [B']              start of each head's stream in uint4 (16-byte) units
+ *   K tile id = (token/64)*D + d            -> 64 consecutive tokens of channel d
+ *   V tile id = (token/64)*D + (c/64)*64 + token%64 -> 64 consecutive channels of one token
+ *   B' = batch * kv_heads, tiles = T*D/64, D = head_dim (this build: D == 128).
+ */
+#ifndef MUSTAFAR_HIP_H
+#define MUSTAFAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUSTAFAR_EINVAL 1 /* == hipErrorInvalidValue */
+
+/* Version / build probe: returns MAJOR*100 + MINOR. */
+int mustafar_abi_version(void);
+
+/*
+ * Key SpMV.  Replaces `Key_SplitK_API` (kernel/build/SpMM_API.cuh:46-64; kernel/csrc/SpMM_API.cu:86-139),
+ * the function `mustafar_key_formulation` calls (kernel/kernel_wrapper/mustafar_wrapper.cu:113-130).
+ *   C[b, n, m] = fp16( sum_k fp32(Khat_g[m, k]) * fp32(B[b, n, k]) ),  g = b / num_key_value_groups
+ *   A           unused (NULL in the reference too)
+ *   B           fp16 [Batch_Size, N_Global, K_Global]   (query rows; the reference pads to N_Global = 8)
+ *   C           fp16 [Batch_Size, N_Global, M_Global]   every element is written (no pre-zeroing needed)
+ *   M_Global    = compressed tokens T (multiple of 64), K_Global = head_dim (128)
+ *   N_Global    1 or 8 (the reference supports only 8; 1 is the un-padded fast form)
+ *   Reduction_Workspace, Split_K   accepted for signature parity; unused (Split_K must be 1)
+ */
+int Key_SplitK_API(void* stream, const void* A, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
+                   const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,
+                   void* Reduction_Workspace, int Split_K, int Batch_Size, int num_key_value_groups);
+
+/*
+ * Value SpMV.  Replaces `Value_SplitK_API` (kernel/build/SpMM_API.cuh:92-110; SpMM_API.cu:193-254),
+ * called by `mustafar_value_formulation` (mustafar_wrapper.cu:242-260).
+ *   C[b, n, m] = fp16( sum_k fp32(Vhat_g[k, m]) * fp32(B[b, n, k]) )
+ *   B           fp16 [Batch_Size, N_Global, K_Global]   (softmax probabilities, K_Global = T)
+ *   C           fp16 [Batch_Size, N_Global, M_Global]   M_Global = head_dim (128)
+ *   Split_K     number of token chunks processed by independent workgroups (>= 1).  The reference
+ *               carries the parameter but pins it to 1 (mustafar_wrapper.cu:199); here it is live:
+ *               use mustafar_value_pick_split_k().  With Split_K > 1, Reduction_Workspace must hold
+ *               mustafar_value_workspace_bytes() bytes (fp32 partials + flags; the reference's
+ *               SplitK_Reduction, Reduction_Kernel.cuh:26-48, used fp16 partials).
+ */
+int Value_SplitK_API(void* stream, const void* A, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
+                     const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,
+                     void* Reduction_Workspace, int Split_K, int Batch_Size, int num_key_value_groups);
+
+int     mustafar_value_pick_split_k(int M_Global, int N_Global, int K_Global, int Batch_Size, int num_key_value_groups);
+int64_t mustafar_value_workspace_bytes(int M_Global, int N_Global, int K_Global, int Batch_Size,
+                                       int num_key_value_groups, int Split_K);
+
+/*
+ * Magnitude prune.  Replaces `dh_prune_key` / `dh_prune_value` (models/llama_mustafar_kernel.py:77-153):
+ * per row of D halfs, thr = kth smallest |x| (1-indexed), out = |x| >= thr ? x : x*0 (sign-preserving zero).
+ * `kth` = max(1, int(target_sparsity * D)) is computed by the caller (model :97).  In-place allowed.
+ */
+int mustafar_prune_magnitude(void* stream, const void* x, void* out, int64_t n_rows, int D, int kth);
+
+/*
+ * Compression.  Replaces `convert_key_batched` / `convert_value_batched` (kernel/compression.py:249-432)
+ * as two device passes with one small device->host read between them (the reference needs >= 1 + 2B'):
+ *   pass 1  mustafar_compress_bitmap_{key,value}: x fp16 [B', t, D] (already pruned) ->
+ *           bmp i64 [B', t*D/64], accum i32 [B', t*D/64 + 1] (accum_counts, compression.py:294-298) and
+ *           head_off i64 [B'+1] = exclusive prefix of 2*accum[h][-1] (start of each head in halfs; :302-304).
+ *   pass 2  mustafar_compress_pack_{key,value}: writes every half of nz_flat[0 .. head_off[B'])
+ *           (non-zeros and zero padding; no pre-zeroing needed).
+ */
+int mustafar_compress_bitmap_key(void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
+                                 int64_t* head_off);
+int mustafar_compress_bitmap_value(void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
+                                   int64_t* head_off);
+int mustafar_compress_pack_key(void* stream, const void* x, int Bp, int t, int D, const int64_t* bmp,
+                               const int32_t* accum, const int64_t* head_off, void* nz_flat);
+int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int D, const int64_t* bmp,
+                                 const int32_t* accum, const int64_t* head_off, void* nz_flat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSTAFAR_HIP_H */

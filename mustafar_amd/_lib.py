@@ -1,0 +1,61 @@
+"""ctypes binding of libmustafar_hip.so (the C ABI declared in include/mustafar_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or a symbol is absent this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmustafar_hip.so")
+
+_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+
+# name -> (restype, argtypes); must list every symbol of include/mustafar_hip.h
+SIGNATURES = {
+    "mustafar_abi_version": (_i32, []),
+    "Key_SplitK_API": (_i32, [_vp] * 8 + [_i32] * 3 + [_vp] + [_i32] * 3),
+    "Value_SplitK_API": (_i32, [_vp] * 8 + [_i32] * 3 + [_vp] + [_i32] * 3),
+    "mustafar_value_pick_split_k": (_i32, [_i32] * 5),
+    "mustafar_value_workspace_bytes": (_i64, [_i32] * 6),
+    "mustafar_prune_magnitude": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32]),
+    "mustafar_compress_bitmap_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mustafar_compress_bitmap_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mustafar_compress_pack_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mustafar_compress_pack_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class MustafarLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library (once).  Raises MustafarLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MustafarLibraryError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (or mustafar_amd/csrc/build.sh). "
+            "mustafar_amd has no CPU fallback.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. ROCm runtime libraries missing
+        raise MustafarLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise MustafarLibraryError(f"{LIB_PATH} lacks symbol {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(err: int, what: str) -> None:
+    if err != 0:
+        raise RuntimeError(f"{what} failed: HIP error {err}" + (" (invalid argument)" if err == 1 else ""))

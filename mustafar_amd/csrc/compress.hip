@@ -1,0 +1,289 @@
+// compress.hip -- per-token magnitude pruning and bitmap/offset compression of K and V for gfx950.
+//
+// Replaces, behind the C ABI of include/mustafar_hip.h:
+//   dh_prune_key / dh_prune_value            models/llama_mustafar_kernel.py:77-153   (torch.kthvalue + 3 passes)
+//   calculate_bitmap_{key,value}_batched     kernel/compression.py:8-115              (Triton, 64-lane programs)
+//   compress_{key,value}_batched             kernel/compression.py:117-247            (Triton)
+//   the torch glue between them              kernel/compression.py:294-309            (cumsum, cat, .item())
+//
+// wave64 makes the format's 64-element tile exactly one wavefront: __ballot() of (x != 0) IS the tile's
+// bitmap (bit-reversed, the format is MSB-first), s_bcnt1 its population count and v_mbcnt the in-tile
+// exclusive prefix that the Triton code computes with tl.cumsum.  All integer work; results are bit-exact.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mustafar_hip.h"
+
+namespace {
+
+constexpr int kD       = 128;
+constexpr int kThreads = 256;
+constexpr int kWaves   = 4;
+
+__device__ __forceinline__ bool nonzero_h(uint16_t v) { return (v & 0x7fffu) != 0; }   // -0.0 is zero, NaN is not
+
+// ------------------------------------------------------------------------------------------------ prune
+// One wave per row of 128 halfs; lane l holds elements 2l and 2l+1.  Exact k-th smallest magnitude by a
+// 15-step radix select on the fp16 magnitude bits (monotone as unsigned integers for non-NaN values).
+__global__ __launch_bounds__(kThreads) void prune_magnitude_kernel(const uint32_t* __restrict__ x,
+                                                                   uint32_t* __restrict__ out, int64_t n_rows, int kth)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < n_rows; row += (int64_t)gridDim.x * kWaves) {
+        const uint32_t w  = x[row * (kD / 2) + lane];
+        const uint32_t m0 = w & 0x7fffu, m1 = (w >> 16) & 0x7fffu;
+        uint32_t prefix = 0, mask = 0;
+        int k = kth;   // 1-indexed rank still to find among the candidates
+#pragma unroll
+        for (int bit = 14; bit >= 0; bit--) {
+            const uint32_t b = 1u << bit;
+            const bool c0 = ((m0 & mask) == prefix) && !(m0 & b);
+            const bool c1 = ((m1 & mask) == prefix) && !(m1 & b);
+            const int zeros = __popcll(__ballot(c0)) + __popcll(__ballot(c1));
+            if (k > zeros) {
+                k -= zeros;
+                prefix |= b;
+            }
+            mask |= b;
+        }
+        const uint32_t thr = prefix;   // == kthvalue(|x|, kth)  (llama_mustafar_kernel.py:103)
+        // keep |x| >= thr (:107); pruned entries become x * 0 = sign-preserving zero (:110)
+        const uint32_t lo = (m0 >= thr) ? (w & 0xffffu) : (w & 0x8000u);
+        const uint32_t hi = (m1 >= thr) ? (w & 0xffff0000u) : (w & 0x80000000u);
+        out[row * (kD / 2) + lane] = lo | hi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bitmaps
+// grid: x = token block (64 tokens), y = head.  Writes the 128 bitmaps of the block and the raw padded
+// counts (half2 units) into accum[h][tile + 1]; the scan kernel turns them into the exclusive prefix.
+
+// V: tile (tb, half, r) = channels half*64..+63 of token tb*64+r (compression.py:87-97); lane = channel.
+__global__ __launch_bounds__(kThreads) void bitmap_value_kernel(const uint16_t* __restrict__ x, int t,
+                                                                int64_t* __restrict__ bmp, int32_t* __restrict__ accum)
+{
+    __shared__ uint64_t s_bmp[kD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tb = blockIdx.x, h = blockIdx.y;
+    const int64_t tiles = (int64_t)t * kD / 64;
+    const uint16_t* xb = x + ((int64_t)h * t + (int64_t)tb * 64) * kD;
+    for (int r = wave; r < 64; r += kWaves) {
+        const uint16_t a = xb[r * kD + lane], b = xb[r * kD + 64 + lane];
+        const uint64_t m0 = __builtin_bitreverse64(__ballot(nonzero_h(a)));
+        const uint64_t m1 = __builtin_bitreverse64(__ballot(nonzero_h(b)));
+        if (lane == 0) {
+            s_bmp[r]      = m0;
+            s_bmp[64 + r] = m1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kD) {
+        const uint64_t m = s_bmp[threadIdx.x];
+        const int64_t tile = (int64_t)tb * kD + threadIdx.x;
+        bmp[h * tiles + tile] = (int64_t)m;
+        accum[h * (tiles + 1) + tile + 1] = ((__popcll(m) + 7) & ~7) >> 1;   // compression.py:46-48
+    }
+}
+
+// K: tile (tb, d) = tokens tb*64..+63 of channel d (compression.py:32-36 on the transposed input); lane = token.
+// The 64x128 block is staged through LDS (row stride 65 dwords: conflict-free column reads).
+constexpr int kRowWords = kD / 2 + 1;
+
+__device__ __forceinline__ void load_block_transposable(uint32_t* s_blk, const uint16_t* __restrict__ xb)
+{
+    // 64 rows x 256 B; thread i copies 16-byte pieces i, i+256, ... (coalesced), scattered into padded rows
+    const uint4* src = reinterpret_cast<const uint4*>(xb);
+    for (int p = threadIdx.x; p < 64 * (kD / 8); p += kThreads) {
+        const uint4 v = src[p];
+        const int row = p / (kD / 8), c4 = p % (kD / 8);
+        uint32_t* dst = s_blk + row * kRowWords + c4 * 4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+
+__device__ __forceinline__ uint16_t block_elem(const uint32_t* s_blk, int token, int d)
+{
+    const uint32_t w = s_blk[token * kRowWords + (d >> 1)];
+    return (uint16_t)((d & 1) ? (w >> 16) : (w & 0xffffu));
+}
+
+__global__ __launch_bounds__(kThreads) void bitmap_key_kernel(const uint16_t* __restrict__ x, int t,
+                                                              int64_t* __restrict__ bmp, int32_t* __restrict__ accum)
+{
+    __shared__ uint32_t s_blk[64 * kRowWords];
+    __shared__ uint64_t s_bmp[kD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tb = blockIdx.x, h = blockIdx.y;
+    const int64_t tiles = (int64_t)t * kD / 64;
+    load_block_transposable(s_blk, x + ((int64_t)h * t + (int64_t)tb * 64) * kD);
+    __syncthreads();
+    for (int d = wave; d < kD; d += kWaves) {
+        const uint64_t m = __builtin_bitreverse64(__ballot(nonzero_h(block_elem(s_blk, lane, d))));
+        if (lane == 0) s_bmp[d] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < kD) {
+        const uint64_t m = s_bmp[threadIdx.x];
+        const int64_t tile = (int64_t)tb * kD + threadIdx.x;
+        bmp[h * tiles + tile] = (int64_t)m;
+        accum[h * (tiles + 1) + tile + 1] = ((__popcll(m) + 7) & ~7) >> 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scan
+// accum[h][0] = 0, accum[h][i+1] = sum of raw counts [0..i]  (torch.cumsum + cat, compression.py:294-298).
+// One workgroup per head walks the tiles 256 at a time with a running carry.
+__global__ __launch_bounds__(kThreads) void scan_counts_kernel(int32_t* __restrict__ accum, int64_t tiles,
+                                                               int64_t* __restrict__ totals)
+{
+    __shared__ int32_t s_wave[kWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* a = accum + (int64_t)blockIdx.x * (tiles + 1);
+    int32_t carry = 0;
+    for (int64_t base = 0; base < tiles; base += kThreads) {
+        const int64_t i = base + threadIdx.x;
+        int32_t v = (i < tiles) ? a[i + 1] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {   // inclusive scan inside the wave
+            const int32_t u = __shfl_up(v, o);
+            if (lane >= o) v += u;
+        }
+        if (lane == 63) s_wave[wave] = v;
+        __syncthreads();
+        int32_t add = carry;
+        for (int w = 0; w < wave; w++) add += s_wave[w];
+        const int32_t blk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (i < tiles) a[i + 1] = v + add;
+        carry += blk_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a[0] = 0;
+        totals[blockIdx.x] = 2 * (int64_t)carry;   // halfs in this head's stream (compression.py:302)
+    }
+}
+
+// head_off[h] = exclusive prefix of totals (compression.py:303-304), head_off[B'] = grand total.  In place.
+__global__ void head_offsets_kernel(int64_t* __restrict__ head_off, int Bp)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t run = 0;
+        for (int h = 0; h < Bp; h++) {
+            const int64_t tot = head_off[h];
+            head_off[h] = run;
+            run += tot;
+        }
+        head_off[Bp] = run;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pack
+// Non-zeros of a tile in ascending element order at stream offset 2*accum[tile] (compression.py:164-174),
+// then zeros up to ceil8(nnz) (the reference relies on a pre-zeroed buffer, :309; here the wave writes them).
+__device__ __forceinline__ void pack_tile(uint16_t* __restrict__ dst, uint16_t v, int lane)
+{
+    const uint64_t m = __ballot(nonzero_h(v));   // bit l <=> element l
+    const int nnz = __popcll(m);
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if ((m >> lane) & 1ull) dst[rank] = v;
+    const int padded = (nnz + 7) & ~7;
+    if (lane >= nnz && lane < padded) dst[lane] = 0;
+}
+
+__global__ __launch_bounds__(kThreads) void pack_value_kernel(const uint16_t* __restrict__ x, int t,
+                                                              const int32_t* __restrict__ accum,
+                                                              const int64_t* __restrict__ head_off,
+                                                              uint16_t* __restrict__ nz)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tb = blockIdx.x, h = blockIdx.y;
+    const int64_t tiles = (int64_t)t * kD / 64;
+    const uint16_t* xb = x + ((int64_t)h * t + (int64_t)tb * 64) * kD;
+    const int32_t* acc = accum + (int64_t)h * (tiles + 1) + (int64_t)tb * kD;
+    uint16_t* nz_h = nz + head_off[h];
+    for (int r = wave; r < 64; r += kWaves) {
+        pack_tile(nz_h + 2 * (int64_t)acc[r], xb[r * kD + lane], lane);
+        pack_tile(nz_h + 2 * (int64_t)acc[64 + r], xb[r * kD + 64 + lane], lane);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void pack_key_kernel(const uint16_t* __restrict__ x, int t,
+                                                            const int32_t* __restrict__ accum,
+                                                            const int64_t* __restrict__ head_off,
+                                                            uint16_t* __restrict__ nz)
+{
+    __shared__ uint32_t s_blk[64 * kRowWords];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tb = blockIdx.x, h = blockIdx.y;
+    const int64_t tiles = (int64_t)t * kD / 64;
+    load_block_transposable(s_blk, x + ((int64_t)h * t + (int64_t)tb * 64) * kD);
+    __syncthreads();
+    const int32_t* acc = accum + (int64_t)h * (tiles + 1) + (int64_t)tb * kD;
+    uint16_t* nz_h = nz + head_off[h];
+    for (int d = wave; d < kD; d += kWaves)
+        pack_tile(nz_h + 2 * (int64_t)acc[d], block_elem(s_blk, lane, d), lane);
+}
+
+int bitmap_common(bool key, void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
+                  int64_t* head_off)
+{
+    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || !head_off) return MUSTAFAR_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(t / 64, Bp);
+    const int64_t tiles = (int64_t)t * kD / 64;
+    auto xs = static_cast<const uint16_t*>(x);
+    if (key) bitmap_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum);
+    else     bitmap_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum);
+    scan_counts_kernel<<<Bp, kThreads, 0, st>>>(accum, tiles, head_off);
+    head_offsets_kernel<<<1, 64, 0, st>>>(head_off, Bp);
+    return (int)hipGetLastError();
+}
+
+int pack_common(bool key, void* stream, const void* x, int Bp, int t, int D, const int32_t* accum,
+                const int64_t* head_off, void* nz_flat)
+{
+    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !accum || !head_off) return MUSTAFAR_EINVAL;
+    if (!nz_flat) return 0;   // nothing to write: every tile of every head is empty
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(t / 64, Bp);
+    auto xs = static_cast<const uint16_t*>(x);
+    auto nz = static_cast<uint16_t*>(nz_flat);
+    if (key) pack_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, accum, head_off, nz);
+    else     pack_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, accum, head_off, nz);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int mustafar_prune_magnitude(void* stream, const void* x, void* out, int64_t n_rows, int D, int kth)
+{
+    if (D != kD || kth < 1 || kth > D || n_rows < 0 || !x || !out) return MUSTAFAR_EINVAL;
+    if (n_rows == 0) return 0;
+    const int64_t blocks = (n_rows + kWaves - 1) / kWaves;
+    const unsigned grid = (unsigned)(blocks < 16384 ? blocks : 16384);
+    prune_magnitude_kernel<<<grid, kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const uint32_t*>(x), static_cast<uint32_t*>(out), n_rows, kth);
+    return (int)hipGetLastError();
+}
+
+int mustafar_compress_bitmap_key(void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
+                                 int64_t* head_off)
+{ return bitmap_common(true, stream, x, Bp, t, D, bmp, accum, head_off); }
+
+int mustafar_compress_bitmap_value(void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
+                                   int64_t* head_off)
+{ return bitmap_common(false, stream, x, Bp, t, D, bmp, accum, head_off); }
+
+int mustafar_compress_pack_key(void* stream, const void* x, int Bp, int t, int D, const int64_t* /*bmp*/,
+                               const int32_t* accum, const int64_t* head_off, void* nz_flat)
+{ return pack_common(true, stream, x, Bp, t, D, accum, head_off, nz_flat); }
+
+int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int D, const int64_t* /*bmp*/,
+                                 const int32_t* accum, const int64_t* head_off, void* nz_flat)
+{ return pack_common(false, stream, x, Bp, t, D, accum, head_off, nz_flat); }
+
+}  // extern "C"

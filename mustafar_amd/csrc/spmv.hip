@@ -1,0 +1,518 @@
+// spmv.hip -- batched sparse q.K^T and p.V over the bitmap-compressed KV cache, for gfx950 (MI355X).
+//
+// Replaces the reference's Key_Kernel / Value_Kernel / SplitK_Reduction
+// (kernel/csrc/SpMM_Kernel.cuh:156-419, :421-676; Reduction_Kernel.cuh:26-48) and their launchers
+// (kernel/csrc/SpMM_API.cu:86-139, :193-254).  Same inputs, same outputs, different algorithm:
+//
+//   * The reference decompresses every tile into a dense shared-memory tile and runs tensor-core MMA
+//     against a query padded to 8 rows (7/8 of the MMA work is padding), once per q-head.
+//   * Here nothing dense is ever materialised and no matrix core is used: the path is HBM-bound.
+//     One wave64 owns a 64-token block of one kv-head = 128 consecutive tiles whose packed non-zeros are
+//     ONE contiguous byte range of the stream.  The range is copied with 16-byte coalesced loads into a
+//     wave-private LDS window (4 chunks of 32 tiles, next chunk prefetched in registers).  For each tile
+//     the 64-bit bitmap lives in an SGPR pair (scalar load): bit-reversed, it is at once the lane mask of
+//     the tile and the input of v_mbcnt, which gives every lane the rank of its element in the packed
+//     stream; one ds_read_u16 fetches the value and v_fma_mix_f32 accumulates in fp32.
+//       K: lane = token  (tile = 64 tokens of one channel),  coefficient = q[d]   -> no cross-lane sum.
+//       V: lane = channel (tile = 64 channels of one token), coefficient = p[t]   -> per-lane sum over
+//          tokens, then a workgroup LDS reduction and (Split_K > 1) fp32 partial slabs + a combine pass.
+//     All q-heads of a GQA group are processed in the same pass, so the compressed bytes are read once
+//     per kv-head rather than once per q-head.
+//
+// Numerics: products fp16 x fp16 are exact in fp32; accumulation is fp32 (order differs from the
+// reference's MMA tree, as any two correct implementations do); final rounding RN to fp16 like
+// __float2half_rn (SpMM_Kernel.cuh:418, :673).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mustafar_hip.h"
+
+namespace {
+
+typedef _Float16 h16;
+
+constexpr int kWaves      = 4;                    // waves per workgroup
+constexpr int kThreads    = 64 * kWaves;
+constexpr int kChunkTiles = 32;                   // tiles staged per LDS chunk
+constexpr int kChunkBytes = kChunkTiles * 128;    // worst case: 64 halfs per tile
+constexpr int kStageBytes = kChunkBytes + 128;    // inactive lanes may read up to 126 B past the data
+constexpr int kD          = 128;                  // head_dim supported by this build
+constexpr int kTilesPerTb = kD;                   // tiles per 64-token block (both formats)
+
+// Register image of one staged chunk (<= 4 KiB, 16-byte granules: 4 x uint4 per lane).
+struct Stage {
+    uint4 r0, r1, r2, r3;
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Issue the global loads of one chunk into registers.  Buffer loads with num_records = chunk length:
+// lanes past the end get zeros from the range check and touch no memory, so there is no branch, no exec
+// masking and nothing is ever read beyond the packed stream.  `src` and `len` are wave-uniform.
+__device__ __forceinline__ Stage stage_issue(const unsigned char* __restrict__ src, uint32_t len, int lane)
+{
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), (short)0, (int)len, 0x00020000);
+    const int off = lane * 16;
+    Stage s;
+    u32x4 t;
+    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);        s.r0 = {t.x, t.y, t.z, t.w};
+    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024, 0, 0); s.r1 = {t.x, t.y, t.z, t.w};
+    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048, 0, 0); s.r2 = {t.x, t.y, t.z, t.w};
+    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072, 0, 0); s.r3 = {t.x, t.y, t.z, t.w};
+    return s;
+}
+
+// Copy the register image into the wave's LDS window (the zero tail is written too: the window is 4 KiB).
+__device__ __forceinline__ void stage_commit(unsigned char* lds, const Stage& s, int lane)
+{
+    uint4* w = reinterpret_cast<uint4*>(lds) + lane;
+    w[0]   = s.r0;
+    w[64]  = s.r1;
+    w[128] = s.r2;
+    w[192] = s.r3;
+}
+
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+
+// Tiles are processed in groups of kGrp inside a REAL (not unrolled) loop, software-pipelined by hand:
+// while the FMAs of group s run, the LDS gathers of group s+1 and the scalar loads of the bitmaps/offsets
+// of group s+2 are in flight.  (Fully unrolled, the compiler floats every scalar bitmap load of a token
+// block to the top of the basic block -- they are invariant loads with no ordering edge -- and spills
+// hundreds of SGPRs through v_writelane; SMEM and LDS also share lgkmcnt, so one drain per group it is.)
+constexpr int kGrp   = 4;
+constexpr int kSteps = kChunkTiles / kGrp;
+
+struct GrpMeta {
+    uint64_t rb[kGrp];    // bit-reversed bitmaps: bit i <=> element i (the format is MSB-first) -- SGPR pairs
+    uint32_t off[kGrp];   // byte offset of each tile's stream inside the LDS window            -- SGPRs
+};
+
+//   bmp/idx : wave-uniform pointers to the group's bitmaps / stream offsets (scalar loads)
+//   idx0    : stream offset (half2 units) of the first byte held in the LDS window
+__device__ __forceinline__ GrpMeta grp_meta(const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx,
+                                            uint32_t idx0)
+{
+    GrpMeta m;
+#pragma unroll
+    for (int j = 0; j < kGrp; j++) {
+        m.rb[j]  = __builtin_bitreverse64(bmp[j]);
+        m.off[j] = (idx[j] - idx0) * 4u;
+    }
+    return m;
+}
+
+struct GrpVals {
+    uint32_t v[kGrp];   // gathered halfs (garbage in lanes whose bit is clear)
+};
+
+__device__ __forceinline__ GrpVals grp_gather(const unsigned char* lds, const GrpMeta& m)
+{
+    GrpVals g;
+#pragma unroll
+    for (int j = 0; j < kGrp; j++) {
+        // rank of this lane's element among the tile's non-zeros = set bits below the lane
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m.rb[j] >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m.rb[j], 0u));
+        g.v[j] = *reinterpret_cast<const uint16_t*>(lds + (rank << 1) + m.off[j]);
+    }
+    return g;
+}
+
+//   cw : coefficient words (2 halfs each) of head 0 for this group's tiles; head stride `chead` (32-bit words)
+template <int G>
+__device__ __forceinline__ void grp_fma(const GrpMeta& m, const GrpVals& g, const uint32_t* __restrict__ cw,
+                                        uint32_t chead, float (&acc)[G])
+{
+    h16 x[kGrp];
+#pragma unroll
+    for (int j = 0; j < kGrp; j++) {
+        const bool on = __builtin_amdgcn_inverse_ballot_w64(m.rb[j]);   // SGPR pair used directly as lane mask
+        x[j] = __builtin_bit_cast(h16, on ? (uint16_t)g.v[j] : (uint16_t)0);
+    }
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        const h16x2* c = reinterpret_cast<const h16x2*>(cw + h * chead);
+        float a = acc[h];
+#pragma unroll
+        for (int jj = 0; jj < kGrp / 2; jj++) {
+            const h16x2 w = c[jj];   // one SGPR, halves picked by op_sel of v_fma_mix_f32
+            a = __builtin_fmaf((float)x[2 * jj], (float)w.x, a);
+            a = __builtin_fmaf((float)x[2 * jj + 1], (float)w.y, a);
+        }
+        acc[h] = a;
+    }
+}
+
+// One staged chunk = 32 tiles.
+template <int G>
+__device__ __forceinline__ void chunk32(const unsigned char* lds, const uint64_t* __restrict__ bmp,
+                                        const uint32_t* __restrict__ idx, uint32_t idx0,
+                                        const uint32_t* __restrict__ cw, uint32_t chead, float (&acc)[G])
+{
+    GrpMeta m_cur = grp_meta(bmp, idx, idx0);
+    GrpVals v_cur = grp_gather(lds, m_cur);
+    GrpMeta m_nxt = grp_meta(bmp + kGrp, idx + kGrp, idx0);
+#pragma unroll 1
+    for (int s = 0; s < kSteps - 1; s++) {
+        const GrpVals v_nxt = grp_gather(lds, m_nxt);
+        const int s2 = min(s + 2, kSteps - 1);   // last iteration reloads the last group (harmless)
+        const GrpMeta m_nn = grp_meta(bmp + s2 * kGrp, idx + s2 * kGrp, idx0);
+        grp_fma<G>(m_cur, v_cur, cw + s * (kGrp / 2), chead, acc);
+        m_cur = m_nxt;
+        v_cur = v_nxt;
+        m_nxt = m_nn;
+    }
+    grp_fma<G>(m_cur, v_cur, cw + (kSteps - 1) * (kGrp / 2), chead, acc);
+}
+
+__device__ __forceinline__ uint32_t nzbits(uint4 v)
+{
+    return (v.x | v.y | v.z | v.w) & 0x7fff7fffu;   // -0.0 counts as zero
+}
+
+// Bit n (1 <= n < N) of the result is set iff pad row n of the dense operand holds a non-zero for any
+// of the G heads over [col0, col0 + ncols) (ncols % 8 == 0).  The hook pads rows 1..7 with zeros
+// (llama_mustafar_kernel.py:273, :313); the reference kernel computes them anyway, so a set bit makes the
+// workgroup compute that row too, a clear bit makes it write exact zeros.  Uniform over the workgroup.
+template <int G>
+__device__ __forceinline__ uint32_t pad_row_mask(const h16* __restrict__ dense, int64_t row_len, int bh0, int N,
+                                                 int col0, int ncols, uint32_t* sh_mask)
+{
+    if (threadIdx.x == 0) *sh_mask = 0u;
+    __syncthreads();
+    const int per_row = ncols / 8;
+    uint32_t mine = 0;
+    for (int u = threadIdx.x; u < G * (N - 1) * per_row; u += kThreads) {
+        const int hn = u / per_row, k = u % per_row;
+        const int h = hn / (N - 1), n = 1 + hn % (N - 1);
+        const uint4 v = *reinterpret_cast<const uint4*>(dense + ((int64_t)(bh0 + h) * N + n) * row_len + col0 + k * 8);
+        if (nzbits(v)) mine |= 1u << n;
+    }
+    if (mine) atomicOr(sh_mask, mine);
+    __syncthreads();
+    return *sh_mask;
+}
+
+// ------------------------------------------------------------------------------------------------ key
+// One 64-token block against coefficient row `qw` (head stride `chead` words) -> acc[h] for lane = token.
+template <int G>
+__device__ __forceinline__ void key_tokblk(unsigned char* lds, const uint64_t* __restrict__ bmp_t,
+                                           const uint32_t* __restrict__ idx_t,
+                                           const unsigned char* __restrict__ nz_h, const uint32_t* __restrict__ qw,
+                                           uint32_t chead, int lane, float (&acc)[G])
+{
+    uint32_t i0 = idx_t[0], i1 = idx_t[kChunkTiles];
+    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (i1 - i0), lane);
+    stage_commit(lds, st, lane);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint32_t n0 = 0, n1 = 0;
+        if (c < 3) {
+            n0 = idx_t[(c + 1) * kChunkTiles];
+            n1 = idx_t[(c + 2) * kChunkTiles];
+            st = stage_issue(nz_h + 4ull * n0, 4u * (n1 - n0), lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        chunk32<G>(lds, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, i0, qw + c * (kChunkTiles / 2), chead, acc);
+        __builtin_amdgcn_wave_barrier();
+        if (c < 3) {
+            stage_commit(lds, st, lane);
+            i0 = n0;
+        }
+    }
+}
+
+// grid: x = ceil(T/256) token super-blocks, y = kv-heads * (groups / G)
+template <int G>
+__global__ __launch_bounds__(kThreads) void key_spmv_kernel(
+    const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
+    const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int N, int groups)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hb_per_kv = groups / G;
+    const int kvh = blockIdx.y / hb_per_kv;
+    const int bh0 = kvh * groups + (blockIdx.y % hb_per_kv) * G;
+    const int ntb = T >> 6;
+    const int tb  = blockIdx.x * kWaves + wave;
+    const int64_t tiles = (int64_t)ntb * kTilesPerTb;
+
+    const uint64_t* bmp_t = bmp + (int64_t)kvh * tiles + (int64_t)tb * kTilesPerTb;
+    const uint32_t* idx_t = idx + (int64_t)kvh * (tiles + 1) + (int64_t)tb * kTilesPerTb;
+    const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
+    unsigned char* lds = smem + wave * kStageBytes;
+    const uint32_t chead = (uint32_t)N * (kD / 2);
+
+    uint32_t rows = 1u;   // bit n: row n has to be computed
+    if (N > 1)
+        rows |= pad_row_mask<G>(q, kD, bh0, N, 0, kD, reinterpret_cast<uint32_t*>(smem + kWaves * kStageBytes));
+
+    const int tok0 = blockIdx.x * kWaves * 64;
+    const int ntok = min(kWaves * 64, T - tok0);
+    for (int n = 0; n < N; n++) {
+        if ((rows >> n) & 1u) {
+            if (tb < ntb) {
+                float acc[G];
+#pragma unroll
+                for (int h = 0; h < G; h++) acc[h] = 0.f;
+                const uint32_t* qw = reinterpret_cast<const uint32_t*>(q + ((int64_t)bh0 * N + n) * kD);
+                key_tokblk<G>(lds, bmp_t, idx_t, nz_h, qw, chead, lane, acc);
+#pragma unroll
+                for (int h = 0; h < G; h++)
+                    out[((int64_t)(bh0 + h) * N + n) * T + (int64_t)tb * 64 + lane] = (h16)acc[h];
+            }
+        } else {   // exact zeros, 16 bytes per lane
+            const int per_row = ntok / 8;
+            const uint4 z = {0u, 0u, 0u, 0u};
+            for (int u = threadIdx.x; u < G * per_row; u += kThreads) {
+                const int h = u / per_row, k = u % per_row;
+                *reinterpret_cast<uint4*>(out + ((int64_t)(bh0 + h) * N + n) * T + tok0 + k * 8) = z;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ value
+// Accumulate token blocks tb_first, tb_first+4, ... < tb_end of one kv-head: lane = channel,
+// acc0 = channels 0..63, acc1 = channels 64..127, coefficient row `pw` (head stride `chead` words).
+template <int G>
+__device__ __forceinline__ void value_tokblks(unsigned char* lds, const uint64_t* __restrict__ bmp_h,
+                                              const uint32_t* __restrict__ idx_h,
+                                              const unsigned char* __restrict__ nz_h, const uint32_t* __restrict__ pw,
+                                              uint32_t chead, int tb_first, int tb_end, int lane,
+                                              float (&acc0)[G], float (&acc1)[G])
+{
+    if (tb_first >= tb_end) return;
+    uint32_t i0 = idx_h[(int64_t)tb_first * kTilesPerTb];
+    Stage st;
+    {
+        const uint32_t i1 = idx_h[(int64_t)tb_first * kTilesPerTb + kChunkTiles];
+        st = stage_issue(nz_h + 4ull * i0, 4u * (i1 - i0), lane);
+        stage_commit(lds, st, lane);
+    }
+    for (int tb = tb_first; tb < tb_end; tb += kWaves) {
+        const uint64_t* bmp_t = bmp_h + (int64_t)tb * kTilesPerTb;
+        const uint32_t* idx_t = idx_h + (int64_t)tb * kTilesPerTb;
+        const bool more = tb + kWaves < tb_end;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            uint32_t n0 = 0, n1 = 0;
+            const bool has_next = (c < 3) || more;
+            if (has_next) {
+                const uint32_t* idx_n = (c < 3) ? idx_t + (c + 1) * kChunkTiles : idx_t + kWaves * kTilesPerTb;
+                n0 = idx_n[0];
+                n1 = idx_n[kChunkTiles];
+                st = stage_issue(nz_h + 4ull * n0, 4u * (n1 - n0), lane);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // chunk c: channel half = c >> 1, tokens (c & 1) * 32 .. +31 of the block
+            const uint32_t* cw = pw + ((uint32_t)tb * 64u + (c & 1) * 32u) / 2u;
+            if (c < 2) chunk32<G>(lds, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, i0, cw, chead, acc0);
+            else       chunk32<G>(lds, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, i0, cw, chead, acc1);
+            __builtin_amdgcn_wave_barrier();
+            if (has_next) {
+                stage_commit(lds, st, lane);
+                i0 = n0;
+            }
+        }
+    }
+}
+
+// grid: x = Split_K token chunks, y = kv-heads * (groups / G)
+//   direct != 0 (one chunk): fp16 results go straight to `out`;
+//   else fp32 partial slabs ws[(s*BH + bh)*N + n][128] + one row mask per workgroup in `flags`.
+template <int G>
+__global__ __launch_bounds__(kThreads) void value_spmv_kernel(
+    const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
+    const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
+    uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16];
+    static_assert(kWaves * kStageBytes >= kWaves * 2 * 4 * 64 * 4, "reduce buffer must fit in the stage area");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hb_per_kv = groups / G;
+    const int kvh = blockIdx.y / hb_per_kv;
+    const int bh0 = kvh * groups + (blockIdx.y % hb_per_kv) * G;
+    const int ntb = T >> 6;
+    const int tb0 = blockIdx.x * tb_per_wg;
+    const int tb_end = min(ntb, tb0 + tb_per_wg);
+    const int64_t tiles = (int64_t)ntb * kTilesPerTb;
+
+    const uint64_t* bmp_h = bmp + (int64_t)kvh * tiles;
+    const uint32_t* idx_h = idx + (int64_t)kvh * (tiles + 1);
+    const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
+    unsigned char* lds = smem + wave * kStageBytes;
+    float* red = reinterpret_cast<float*>(smem);   // [kWaves][2*G][64], overlays the stage windows
+    float* ws_slab = ws + (int64_t)blockIdx.x * BH * N * kD;
+    const uint32_t chead = (uint32_t)N * ((uint32_t)T / 2u);
+
+    uint32_t rows = 1u;
+    if (N > 1) {
+        rows |= pad_row_mask<G>(p, T, bh0, N, tb0 * 64, (tb_end - tb0) * 64,
+                                reinterpret_cast<uint32_t*>(smem + kWaves * kStageBytes));
+        if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + blockIdx.y] = rows;
+    }
+
+    for (int n = 0; n < N; n++) {
+        const bool live = (rows >> n) & 1u;
+        if (!live && !direct) continue;   // the combine pass skips this row of this slab
+        float acc0[G], acc1[G];
+#pragma unroll
+        for (int h = 0; h < G; h++) acc0[h] = acc1[h] = 0.f;
+        if (live) {
+            const uint32_t* pw = reinterpret_cast<const uint32_t*>(p + ((int64_t)bh0 * N + n) * T);
+            value_tokblks<G>(lds, bmp_h, idx_h, nz_h, pw, chead, tb0 + wave, tb_end, lane, acc0, acc1);
+        }
+        __syncthreads();   // every wave is done with its stage window (and with the previous row's sums)
+#pragma unroll
+        for (int h = 0; h < G; h++) {
+            red[(wave * 2 * G + h) * 64 + lane]     = acc0[h];
+            red[(wave * 2 * G + G + h) * 64 + lane] = acc1[h];
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < 2 * G * 64; o += kThreads) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; w++) s += red[w * 2 * G * 64 + o];
+            const int hh = o >> 6, l = o & 63;   // hh = half * G + h
+            const int64_t row = (int64_t)(bh0 + hh % G) * N + n;
+            if (direct) out[row * kD + (hh / G) * 64 + l] = (h16)s;
+            else        ws_slab[row * kD + (hh / G) * 64 + l] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// out[bh, n, c] = fp16( sum_s ws[s, bh, n, c] ), pad rows only from the slabs whose row mask has them.
+// (the role of the reference's SplitK_Reduction, Reduction_Kernel.cuh:26-48, with fp32 partials)
+__global__ __launch_bounds__(256) void value_combine_kernel(const float* __restrict__ ws,
+                                                            const uint32_t* __restrict__ flags, h16* __restrict__ out,
+                                                            int BH, int N, int S, int groups, int G)
+{
+    const int64_t total = (int64_t)BH * N * kD;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int n  = (int)((i / kD) % N);
+    const int bh = (int)(i / ((int64_t)kD * N));
+    const int hb_per_kv = groups / G;
+    const int y  = (bh / groups) * hb_per_kv + (bh % groups) / G;   // blockIdx.y of the producer
+    const int gy = (BH / groups) * hb_per_kv;
+    float s = 0.f;
+    for (int k = 0; k < S; k++)
+        if (n == 0 || ((flags[k * gy + y] >> n) & 1u)) s += ws[(int64_t)k * total + i];
+    out[i] = (h16)s;
+}
+
+inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : 1; }
+
+}  // namespace
+
+extern "C" {
+
+int mustafar_abi_version(void) { return 100; }
+
+int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
+                   const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,
+                   void* /*Reduction_Workspace*/, int Split_K, int Batch_Size, int num_key_value_groups)
+{
+    const int T = M_Global, N = N_Global, groups = num_key_value_groups;
+    if (K_Global != kD || T <= 0 || (T & 63) || (N != 1 && N != 8) || Split_K != 1 || groups < 1 ||
+        Batch_Size < 1 || Batch_Size % groups)
+        return MUSTAFAR_EINVAL;
+    if (!bmp || !NZ || !idx || !NZ_offset || !B || !C) return MUSTAFAR_EINVAL;
+    const int G = pick_g(groups);
+    const dim3 grid((T / 64 + kWaves - 1) / kWaves, (Batch_Size / groups) * (groups / G));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto nz = static_cast<const unsigned char*>(NZ);
+    auto q  = static_cast<const h16*>(B);
+    auto o  = static_cast<h16*>(C);
+    switch (G) {
+        case 4: key_spmv_kernel<4><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups); break;
+        case 2: key_spmv_kernel<2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups); break;
+        default: key_spmv_kernel<1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups); break;
+    }
+    return (int)hipGetLastError();
+}
+
+int mustafar_value_pick_split_k(int M_Global, int N_Global, int K_Global, int Batch_Size, int num_key_value_groups)
+{
+    (void)N_Global;
+    if (M_Global != kD || K_Global <= 0 || (K_Global & 63) || num_key_value_groups < 1 || Batch_Size < 1) return 1;
+    const int ntb = K_Global / 64;
+    const int G = pick_g(num_key_value_groups);
+    const int gy = (Batch_Size / num_key_value_groups) * (num_key_value_groups / G);
+    // aim at ~8 workgroups per CU (256 CUs), at least one token block per wave
+    int want = (2048 + gy - 1) / gy;
+    int max_s = (ntb + kWaves - 1) / kWaves;
+    int s = want < 1 ? 1 : want;
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    // normalise so that every chunk is non-empty
+    const int tb_per_wg = (ntb + s - 1) / s;
+    return (ntb + tb_per_wg - 1) / tb_per_wg;
+}
+
+int64_t mustafar_value_workspace_bytes(int M_Global, int N_Global, int K_Global, int Batch_Size,
+                                       int num_key_value_groups, int Split_K)
+{
+    (void)K_Global;
+    if (Split_K <= 1) return 0;
+    const int G = pick_g(num_key_value_groups);
+    const int64_t gy = (int64_t)(Batch_Size / num_key_value_groups) * (num_key_value_groups / G);
+    const int64_t slabs = (int64_t)Split_K * Batch_Size * N_Global * M_Global * (int64_t)sizeof(float);
+    return slabs + ((Split_K * gy * (int64_t)sizeof(uint32_t) + 255) / 256) * 256;
+}
+
+int Value_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
+                     const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,
+                     void* Reduction_Workspace, int Split_K, int Batch_Size, int num_key_value_groups)
+{
+    const int T = K_Global, N = N_Global, groups = num_key_value_groups;
+    if (M_Global != kD || T <= 0 || (T & 63) || (N != 1 && N != 8) || Split_K < 1 || groups < 1 ||
+        Batch_Size < 1 || Batch_Size % groups)
+        return MUSTAFAR_EINVAL;
+    if (!bmp || !NZ || !idx || !NZ_offset || !B || !C) return MUSTAFAR_EINVAL;
+    if (Split_K > 1 && !Reduction_Workspace) return MUSTAFAR_EINVAL;
+    const int ntb = T / 64;
+    const int G = pick_g(groups);
+    const int gy = (Batch_Size / groups) * (groups / G);
+    const int tb_per_wg = (ntb + Split_K - 1) / Split_K;
+    const int S = (ntb + tb_per_wg - 1) / tb_per_wg;   // non-empty chunks (<= Split_K)
+    const int direct = (S == 1);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto nz = static_cast<const unsigned char*>(NZ);
+    auto p  = static_cast<const h16*>(B);
+    auto o  = static_cast<h16*>(C);
+    float* ws = static_cast<float*>(Reduction_Workspace);
+    uint32_t* flags = nullptr;
+    if (!direct) {
+        const int64_t slabs = (int64_t)Split_K * Batch_Size * N * kD * (int64_t)sizeof(float);
+        flags = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(Reduction_Workspace) + slabs);
+    }
+    const dim3 grid(S, gy);
+    switch (G) {
+        case 4:
+            value_spmv_kernel<4><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
+                                                            Batch_Size, tb_per_wg, direct);
+            break;
+        case 2:
+            value_spmv_kernel<2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
+                                                            Batch_Size, tb_per_wg, direct);
+            break;
+        default:
+            value_spmv_kernel<1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
+                                                            Batch_Size, tb_per_wg, direct);
+            break;
+    }
+    int err = (int)hipGetLastError();
+    if (err || direct) return err;
+    const int64_t total = (int64_t)Batch_Size * N * kD;
+    value_combine_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(ws, flags, o, Batch_Size, N, S, groups, G);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

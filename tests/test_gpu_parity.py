@@ -1,0 +1,253 @@
+"""GPU: HIP path (through the C ABI / mustafar_package mirror) against the CPU oracle and golden fixtures.
+
+Integer/byte results (prune, bitmaps, offsets, packed stream) must be bit-exact.  The two SpMV results are
+fp16 roundings of fp32 sums: they must sit within `fp16_bound` of the oracle's float64 sums (tolerance
+stated in tests/util.py) -- the same bound the oracle's own fp16 output satisfies.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.util import fp16_bound, make_cache
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    from mustafar_amd import compression, mustafar_package
+    return mustafar_package, compression
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(DEV) if dtype is None else t.to(DEV, dtype)
+
+
+def _cache_to_dev(c):
+    return (_t(c["bmp"]), _t(np.concatenate(c["nzs"]) if len(c["nzs"]) else np.zeros(0, np.float16)),
+            _t(c["idx"]), _t(c["nz_offset"]))
+
+
+def _check_spmv(got, C16, Cd, sumabs, what):
+    got = got.float().cpu().numpy().astype(np.float64)
+    bound = fp16_bound(Cd, sumabs)
+    err = np.abs(got - Cd)
+    assert (err <= bound).all(), f"{what}: max excess {np.max(err - bound):.3e} at {np.unravel_index(np.argmax(err - bound), err.shape)}"
+    assert (np.abs(C16.astype(np.float64) - Cd) <= bound).all(), "oracle itself violates the bound"
+
+
+@pytest.mark.parametrize("groups,N,B,t,s,adv", [
+    (1, 8, 2, 256, 0.7, False), (4, 8, 2, 256, 0.7, False), (4, 1, 3, 320, 0.5, False), (2, 1, 2, 64, 0.8, False),
+    (1, 1, 1, 1024, 0.7, False), (4, 8, 1, 512, 0.8, True), (8, 1, 1, 192, 0.7, False), (3, 8, 2, 128, 0.7, False),
+])
+def test_key_spmv_vs_oracle(pkg, groups, N, B, t, s, adv):
+    mp, _ = pkg
+    c = make_cache("key", B, t, 128, s, seed=100 + t + groups, adversarial=adv)
+    BH = B * groups
+    rng = np.random.default_rng(5)
+    q = np.zeros((BH, N, 128), np.float16)
+    q[:, 0] = rng.standard_normal((BH, 128)).astype(np.float16)          # hook layout: row 0 real, rows 1.. zero
+    bmp, nz, idx, off = _cache_to_dev(c)
+    out = mp.mustafar_key_formulation(bmp, nz, idx, off, _t(q), t, 128, BH, groups)
+    assert out.shape == (BH, N, t) and out.dtype == torch.float16
+    C16, Cd = orc.key_spmv(c["bmp"], np.concatenate(c["nzs"]), c["idx"], c["nz_offset"], q, t, 128, BH, groups)
+    K = c["pruned"].astype(np.float64)
+    sumabs = np.stack([np.abs(K[b // groups]) @ np.abs(q[b].astype(np.float64)).T for b in range(BH)]).transpose(0, 2, 1)
+    _check_spmv(out, C16, Cd, sumabs, "key")
+    if N == 8:
+        assert not out[:, 1:].any(), "pad rows must be exact zeros"
+
+
+@pytest.mark.parametrize("groups", [1, 4])
+def test_key_spmv_nonzero_pad_rows(pkg, groups):
+    """The reference computes all 8 rows of the padded query; so must we when they are not zero."""
+    mp, _ = pkg
+    B, t = 2, 256
+    c = make_cache("key", B, t, 128, 0.7, seed=77)
+    BH = B * groups
+    rng = np.random.default_rng(6)
+    q = rng.standard_normal((BH, 8, 128)).astype(np.float16)
+    q[:, 2] = 0
+    q[0, 5] = 0
+    q[:, 6, ::2] = np.float16(-0.0)
+    bmp, nz, idx, off = _cache_to_dev(c)
+    out = mp.mustafar_key_formulation(bmp, nz, idx, off, _t(q), t, 128, BH, groups)
+    C16, Cd = orc.key_spmv(c["bmp"], np.concatenate(c["nzs"]), c["idx"], c["nz_offset"], q, t, 128, BH, groups)
+    K = c["pruned"].astype(np.float64)
+    sumabs = np.stack([np.abs(K[b // groups]) @ np.abs(q[b].astype(np.float64)).T for b in range(BH)]).transpose(0, 2, 1)
+    _check_spmv(out, C16, Cd, sumabs, "key-8rows")
+
+
+@pytest.mark.parametrize("groups,N,B,t,s,split,adv", [
+    (1, 8, 2, 256, 0.7, 0, False), (4, 8, 2, 256, 0.7, 0, False), (4, 1, 3, 320, 0.5, 0, False),
+    (2, 1, 2, 64, 0.8, 0, False), (1, 1, 1, 1024, 0.7, 1, False), (4, 1, 1, 1024, 0.7, 3, False),
+    (4, 8, 1, 512, 0.8, 0, True), (8, 1, 1, 192, 0.7, 2, False), (3, 8, 2, 128, 0.7, 1, False),
+    (4, 8, 1, 1024, 0.7, 5, False),
+])
+def test_value_spmv_vs_oracle(pkg, groups, N, B, t, s, split, adv):
+    mp, _ = pkg
+    c = make_cache("value", B, t, 128, s, seed=200 + t + groups, adversarial=adv)
+    BH = B * groups
+    rng = np.random.default_rng(8)
+    p = np.zeros((BH, N, t), np.float16)
+    logits = rng.standard_normal((BH, t)) * 2
+    p[:, 0] = (np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)).astype(np.float16)
+    bmp, nz, idx, off = _cache_to_dev(c)
+    ws = torch.zeros(1, dtype=torch.float16, device=DEV)             # the model's 1-element workspace (:658)
+    out = mp.mustafar_value_formulation(bmp, nz, idx, off, _t(p), ws, 128, t, BH, groups, split_k=split)
+    assert out.shape == (BH, N, 128) and out.dtype == torch.float16
+    C16, Cd = orc.value_spmv(c["bmp"], np.concatenate(c["nzs"]), c["idx"], c["nz_offset"], p, 128, t, BH, groups)
+    V = c["pruned"].astype(np.float64)
+    sumabs = np.stack([np.abs(p[b].astype(np.float64)) @ np.abs(V[b // groups]) for b in range(BH)])
+    _check_spmv(out, C16, Cd, sumabs, "value")
+    if N == 8:
+        assert not out[:, 1:].any()
+
+
+@pytest.mark.parametrize("groups,split", [(1, 0), (4, 0), (4, 1), (2, 4)])
+def test_value_spmv_nonzero_pad_rows(pkg, groups, split):
+    mp, _ = pkg
+    B, t = 2, 512
+    c = make_cache("value", B, t, 128, 0.7, seed=99)
+    BH = B * groups
+    rng = np.random.default_rng(9)
+    p = (rng.random((BH, 8, t)) / t).astype(np.float16)
+    p[:, 3] = 0
+    p[:, 4, : t // 2] = 0            # non-zero only in the second half of the tokens: per-chunk row masks differ
+    p[1, 7] = 0
+    bmp, nz, idx, off = _cache_to_dev(c)
+    ws = torch.zeros(1, dtype=torch.float16, device=DEV)
+    out = mp.mustafar_value_formulation(bmp, nz, idx, off, _t(p), ws, 128, t, BH, groups, split_k=split)
+    C16, Cd = orc.value_spmv(c["bmp"], np.concatenate(c["nzs"]), c["idx"], c["nz_offset"], p, 128, t, BH, groups)
+    V = c["pruned"].astype(np.float64)
+    sumabs = np.stack([np.abs(p[b].astype(np.float64)) @ np.abs(V[b // groups]) for b in range(BH)])
+    _check_spmv(out, C16, Cd, sumabs, "value-8rows")
+
+
+def test_spmv_on_golden_compressed_streams(pkg, golden_dir):
+    """Feed the REFERENCE-produced compressed tensors (Triton kernels, fixtures) straight to the HIP kernels."""
+    mp, _ = pkg
+    g = np.load(os.path.join(golden_dir, "compress_reference.npz"))
+    rng = np.random.default_rng(11)
+    for name in ("rand_B2_t256_s0.7", "edge_tiles", "rand_B1_t512_s0.7", "rand_B2_t128_s0.0"):
+        x = g[f"{name}__x"].view(np.float16)
+        B, t, D = x.shape
+        for which in ("key", "value"):
+            bmp, accum = g[f"{name}__{which}__bmp"], g[f"{name}__{which}__accum"]
+            packed = g[f"{name}__{which}__packed"].view(np.float16)
+            off = orc.nz_offset_from_idx(accum)
+            groups = 2
+            BH = B * groups
+            if which == "key":
+                q = rng.standard_normal((BH, 1, D)).astype(np.float16)
+                out = mp.mustafar_key_formulation(_t(bmp), _t(packed), _t(accum), _t(off), _t(q), t, D, BH, groups)
+                want = np.stack([x[b // groups].astype(np.float64) @ q[b, 0].astype(np.float64) for b in range(BH)])[:, None]
+                sumabs = np.stack([np.abs(x[b // groups].astype(np.float64)) @ np.abs(q[b, 0].astype(np.float64)) for b in range(BH)])[:, None]
+            else:
+                p = (rng.random((BH, 1, t)) / t).astype(np.float16)
+                ws = torch.zeros(1, dtype=torch.float16, device=DEV)
+                out = mp.mustafar_value_formulation(_t(bmp), _t(packed), _t(accum), _t(off), _t(p), ws, D, t, BH, groups)
+                want = np.stack([p[b, 0].astype(np.float64) @ x[b // groups].astype(np.float64) for b in range(BH)])[:, None]
+                sumabs = np.stack([np.abs(p[b, 0].astype(np.float64)) @ np.abs(x[b // groups].astype(np.float64)) for b in range(BH)])[:, None]
+            err = np.abs(out.float().cpu().numpy().astype(np.float64) - want)
+            assert (err <= fp16_bound(want, sumabs)).all(), (name, which)
+
+
+def test_prune_bit_exact(pkg, golden_dir):
+    _, comp = pkg
+    g = np.load(os.path.join(golden_dir, "prune_reference.npz"))
+    names = sorted({k.split("__")[0] for k in g.files})
+    checked = 0
+    for name in names:
+        x = g[f"{name}__x"]
+        if x.shape[-1] != 128:
+            continue
+        s = float(g[f"{name}__s"])
+        got = comp.prune_magnitude(_t(x.view(np.float16)), s).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, g[f"{name}__y"]), name
+        checked += 1
+    assert checked >= 9
+    rng = np.random.default_rng(3)
+    for s in (0.5, 0.7, 0.8, 0.3):
+        x = rng.standard_normal((3, 5, 77, 128)).astype(np.float16)
+        x[0, 0, :10] = np.round(x[0, 0, :10] * 2) / 2          # ties
+        got = comp.prune_magnitude(_t(x), s).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, orc.prune_magnitude(x, s).view(np.uint16))
+
+
+@pytest.mark.parametrize("which", ["key", "value"])
+def test_compress_bit_exact(pkg, golden_dir, which):
+    _, comp = pkg
+    conv = comp.convert_key_batched if which == "key" else comp.convert_value_batched
+    g = np.load(os.path.join(golden_dir, "compress_reference.npz"))
+    names = sorted({k.split("__")[0] for k in g.files if k.endswith("__x")})
+    checked = 0
+    for name in names:
+        x = g[f"{name}__x"]
+        if x.shape[-1] != 128:
+            continue
+        bmp, accum, nzs = conv(_t(x.view(np.float16)))
+        assert bmp.dtype == torch.int64 and accum.dtype == torch.int32 and len(nzs) == x.shape[0]
+        assert np.array_equal(bmp.cpu().numpy(), g[f"{name}__{which}__bmp"]), name
+        assert np.array_equal(accum.cpu().numpy(), g[f"{name}__{which}__accum"]), name
+        flat = torch.cat(nzs).cpu().numpy().view(np.uint16)
+        assert np.array_equal(flat, g[f"{name}__{which}__packed"]), name
+        checked += 1
+    assert checked >= 8
+    # seeded random, larger than the fixtures, against the oracle
+    for (B, t, s, seed) in [(5, 640, 0.7, 1), (2, 2048, 0.5, 2), (1, 64, 0.8, 3)]:
+        c = make_cache(which, B, t, 128, s, seed)
+        bmp, accum, nzs = conv(_t(c["pruned"]))
+        assert np.array_equal(bmp.cpu().numpy(), c["bmp"])
+        assert np.array_equal(accum.cpu().numpy(), c["idx"])
+        for b in range(B):
+            assert np.array_equal(nzs[b].cpu().numpy().view(np.uint16), c["nzs"][b].view(np.uint16))
+
+
+def test_empty_and_dense_blocks(pkg):
+    """All-zero input (every tile empty, zero-length streams) and fully dense input (nnz = 64 everywhere)."""
+    mp, comp = pkg
+    z = torch.zeros((2, 128, 128), dtype=torch.float16, device=DEV)
+    for conv in (comp.convert_key_batched, comp.convert_value_batched):
+        bmp, accum, nzs = conv(z)
+        assert not bmp.any() and not accum.any() and all(n.numel() == 0 for n in nzs)
+    d = torch.randn((2, 128, 128), device=DEV).half()
+    d[d == 0] = 1
+    q = torch.randn((2, 1, 128), device=DEV).half()
+    bmp, accum, nzs = comp.convert_key_batched(d)
+    assert (bmp == -1).all() and int(accum[0, -1]) == 32 * 256
+    off = torch.tensor([0, nzs[0].numel() // 8], dtype=torch.int32, device=DEV)
+    out = mp.mustafar_key_formulation(bmp, torch.cat(nzs), accum, off, q, 128, 128, 2, 1)
+    want = torch.einsum("btd,bnd->bnt", d.float(), q.float())
+    torch.testing.assert_close(out.float(), want, rtol=2e-3, atol=2e-2)
+    bmp, accum, nzs = comp.convert_value_batched(d)
+    p = torch.softmax(torch.randn((2, 1, 128), device=DEV), -1).half()
+    ws = torch.zeros(1, dtype=torch.float16, device=DEV)
+    out = mp.mustafar_value_formulation(bmp, torch.cat(nzs), accum, off, p, ws, 128, 128, 2, 1)
+    torch.testing.assert_close(out.float(), torch.einsum("bnt,btd->bnd", p.float(), d.float()), rtol=2e-3, atol=2e-3)
+
+
+def test_wrapper_error_behaviour(pkg):
+    """Same exceptions as mustafar_wrapper.cu:36-73 (RuntimeError), plus the added shape validation."""
+    mp, _ = pkg
+    c = make_cache("key", 1, 64, 128, 0.7, seed=1)
+    bmp, nz, idx, off = _cache_to_dev(c)
+    q = torch.zeros((1, 8, 128), dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError, match="float16"):
+        mp.mustafar_key_formulation(bmp, nz, idx, off, q.float(), 64, 128, 1, 1)
+    with pytest.raises(RuntimeError, match="int64"):
+        mp.mustafar_key_formulation(bmp.int(), nz, idx, off, q, 64, 128, 1, 1)
+    with pytest.raises(RuntimeError, match="same device"):
+        mp.mustafar_key_formulation(bmp.cpu(), nz, idx, off, q, 64, 128, 1, 1)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        mp.mustafar_key_formulation(bmp, nz, idx, off, q.transpose(1, 2), 64, 128, 1, 1)
+    with pytest.raises(RuntimeError):
+        mp.mustafar_key_formulation(bmp, nz, idx, off, q, 128, 128, 1, 1)      # T does not match the cache
+    with pytest.raises(RuntimeError):
+        mp.mustafar_key_formulation(bmp, nz, idx, off, q, 64, 64, 1, 1)        # head_dim 64 unsupported
