@@ -76,95 +76,55 @@ __device__ __forceinline__ void stage_commit(unsigned char* lds, const Stage& s,
 
 typedef h16 h16x2 __attribute__((ext_vector_type(2)));
 
-// Tiles are processed in groups of kGrp inside a REAL (not unrolled) loop, software-pipelined by hand:
-// while the FMAs of group s run, the LDS gathers of group s+1 and the scalar loads of the bitmaps/offsets
-// of group s+2 are in flight.  (Fully unrolled, the compiler floats every scalar bitmap load of a token
-// block to the top of the basic block -- they are invariant loads with no ordering edge -- and spills
-// hundreds of SGPRs through v_writelane; SMEM and LDS also share lgkmcnt, so one drain per group it is.)
-constexpr int kGrp   = 4;
-constexpr int kSteps = kChunkTiles / kGrp;
+// Tiles are processed kStep at a time inside a REAL (not unrolled) loop.  Fully unrolled, the compiler
+// floats every scalar bitmap load of a token block to the top of the basic block (invariant loads carry
+// no ordering edge) and spills hundreds of SGPRs through v_writelane.  Latency of the scalar loads and of
+// the LDS gathers is covered by occupancy (7-8 waves per SIMD), not by software pipelining: SMEM and LDS
+// share lgkmcnt and SMEM returns out of order, so every step drains the counter anyway.
+constexpr int kStep = 8;
 
-struct GrpMeta {
-    uint64_t rb[kGrp];    // bit-reversed bitmaps: bit i <=> element i (the format is MSB-first) -- SGPR pairs
-    uint32_t off[kGrp];   // byte offset of each tile's stream inside the LDS window            -- SGPRs
-};
-
-//   bmp/idx : wave-uniform pointers to the group's bitmaps / stream offsets (scalar loads)
-//   idx0    : stream offset (half2 units) of the first byte held in the LDS window
-__device__ __forceinline__ GrpMeta grp_meta(const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx,
-                                            uint32_t idx0)
-{
-    GrpMeta m;
-#pragma unroll
-    for (int j = 0; j < kGrp; j++) {
-        m.rb[j]  = __builtin_bitreverse64(bmp[j]);
-        m.off[j] = (idx[j] - idx0) * 4u;
-    }
-    return m;
-}
-
-struct GrpVals {
-    uint32_t v[kGrp];   // gathered halfs (garbage in lanes whose bit is clear)
-};
-
-__device__ __forceinline__ GrpVals grp_gather(const unsigned char* lds, const GrpMeta& m)
-{
-    GrpVals g;
-#pragma unroll
-    for (int j = 0; j < kGrp; j++) {
-        // rank of this lane's element among the tile's non-zeros = set bits below the lane
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m.rb[j] >> 32),
-                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m.rb[j], 0u));
-        g.v[j] = *reinterpret_cast<const uint16_t*>(lds + (rank << 1) + m.off[j]);
-    }
-    return g;
-}
-
-//   cw : coefficient words (2 halfs each) of head 0 for this group's tiles; head stride `chead` (32-bit words)
+//   smem    : base of the workgroup's LDS; `adj` = (this wave's window offset) - 4 * idx0, where idx0 is the
+//             stream offset (half2 units) of the first byte held in the window  -> tile offset = 4*idx + adj
+//   bmp/idx : wave-uniform pointers to the chunk's 32 bitmaps / stream offsets (scalar loads)
+//   cw      : coefficient pairs (2 halfs) of head 0 for the chunk's tiles; head stride `chead` (pairs)
 template <int G>
-__device__ __forceinline__ void grp_fma(const GrpMeta& m, const GrpVals& g, const uint32_t* __restrict__ cw,
+__device__ __forceinline__ void chunk32(const unsigned char* smem, uint32_t adj, const uint64_t* __restrict__ bmp,
+                                        const uint32_t* __restrict__ idx, const h16x2* __restrict__ cw,
                                         uint32_t chead, float (&acc)[G])
 {
-    h16 x[kGrp];
-#pragma unroll
-    for (int j = 0; j < kGrp; j++) {
-        const bool on = __builtin_amdgcn_inverse_ballot_w64(m.rb[j]);   // SGPR pair used directly as lane mask
-        x[j] = __builtin_bit_cast(h16, on ? (uint16_t)g.v[j] : (uint16_t)0);
-    }
-#pragma unroll
-    for (int h = 0; h < G; h++) {
-        const h16x2* c = reinterpret_cast<const h16x2*>(cw + h * chead);
-        float a = acc[h];
-#pragma unroll
-        for (int jj = 0; jj < kGrp / 2; jj++) {
-            const h16x2 w = c[jj];   // one SGPR, halves picked by op_sel of v_fma_mix_f32
-            a = __builtin_fmaf((float)x[2 * jj], (float)w.x, a);
-            a = __builtin_fmaf((float)x[2 * jj + 1], (float)w.y, a);
-        }
-        acc[h] = a;
-    }
-}
-
-// One staged chunk = 32 tiles.
-template <int G>
-__device__ __forceinline__ void chunk32(const unsigned char* lds, const uint64_t* __restrict__ bmp,
-                                        const uint32_t* __restrict__ idx, uint32_t idx0,
-                                        const uint32_t* __restrict__ cw, uint32_t chead, float (&acc)[G])
-{
-    GrpMeta m_cur = grp_meta(bmp, idx, idx0);
-    GrpVals v_cur = grp_gather(lds, m_cur);
-    GrpMeta m_nxt = grp_meta(bmp + kGrp, idx + kGrp, idx0);
 #pragma unroll 1
-    for (int s = 0; s < kSteps - 1; s++) {
-        const GrpVals v_nxt = grp_gather(lds, m_nxt);
-        const int s2 = min(s + 2, kSteps - 1);   // last iteration reloads the last group (harmless)
-        const GrpMeta m_nn = grp_meta(bmp + s2 * kGrp, idx + s2 * kGrp, idx0);
-        grp_fma<G>(m_cur, v_cur, cw + s * (kGrp / 2), chead, acc);
-        m_cur = m_nxt;
-        v_cur = v_nxt;
-        m_nxt = m_nn;
+    for (int s = 0; s < kChunkTiles / kStep; s++) {
+        uint64_t rb[kStep];    // bit-reversed bitmaps: bit i <=> element i (the format is MSB-first) -- SGPR pairs
+        uint32_t off[kStep];   // byte offset of each tile's stream in LDS                           -- SGPRs
+#pragma unroll
+        for (int j = 0; j < kStep; j++) {
+            rb[j]  = __builtin_bitreverse64(bmp[s * kStep + j]);
+            off[j] = idx[s * kStep + j] * 4u + adj;
+        }
+        h16x2 c[G][kStep / 2];
+#pragma unroll
+        for (int h = 0; h < G; h++)
+#pragma unroll
+            for (int jj = 0; jj < kStep / 2; jj++) c[h][jj] = cw[h * chead + s * (kStep / 2) + jj];
+        uint32_t v[kStep];
+#pragma unroll
+        for (int j = 0; j < kStep; j++) {
+            // rank of this lane's element among the tile's non-zeros = set bits below the lane
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rb[j] >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)rb[j], 0u));
+            v[j] = *reinterpret_cast<const uint16_t*>(smem + ((rank << 1) + off[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < kStep; j++) {
+            const bool on = __builtin_amdgcn_inverse_ballot_w64(rb[j]);   // SGPR pair used directly as lane mask
+            const h16 x = __builtin_bit_cast(h16, on ? (uint16_t)v[j] : (uint16_t)0);
+#pragma unroll
+            for (int h = 0; h < G; h++) {
+                const h16 cc = (j & 1) ? c[h][j / 2].y : c[h][j / 2].x;   // op_sel of v_fma_mix_f32 on an SGPR
+                acc[h] = __builtin_fmaf((float)x, (float)cc, acc[h]);
+            }
+        }
     }
-    grp_fma<G>(m_cur, v_cur, cw + (kSteps - 1) * (kGrp / 2), chead, acc);
 }
 
 __device__ __forceinline__ uint32_t nzbits(uint4 v)
@@ -198,11 +158,12 @@ __device__ __forceinline__ uint32_t pad_row_mask(const h16* __restrict__ dense, 
 // ------------------------------------------------------------------------------------------------ key
 // One 64-token block against coefficient row `qw` (head stride `chead` words) -> acc[h] for lane = token.
 template <int G>
-__device__ __forceinline__ void key_tokblk(unsigned char* lds, const uint64_t* __restrict__ bmp_t,
-                                           const uint32_t* __restrict__ idx_t,
-                                           const unsigned char* __restrict__ nz_h, const uint32_t* __restrict__ qw,
+__device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off,
+                                           const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
+                                           const unsigned char* __restrict__ nz_h, const h16x2* __restrict__ qw,
                                            uint32_t chead, int lane, float (&acc)[G])
 {
+    unsigned char* lds = smem + lds_off;
     uint32_t i0 = idx_t[0], i1 = idx_t[kChunkTiles];
     Stage st = stage_issue(nz_h + 4ull * i0, 4u * (i1 - i0), lane);
     stage_commit(lds, st, lane);
@@ -215,7 +176,8 @@ __device__ __forceinline__ void key_tokblk(unsigned char* lds, const uint64_t* _
             st = stage_issue(nz_h + 4ull * n0, 4u * (n1 - n0), lane);
         }
         __builtin_amdgcn_wave_barrier();
-        chunk32<G>(lds, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, i0, qw + c * (kChunkTiles / 2), chead, acc);
+        chunk32<G>(smem, lds_off - 4u * i0, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles,
+                   qw + c * (kChunkTiles / 2), chead, acc);
         __builtin_amdgcn_wave_barrier();
         if (c < 3) {
             stage_commit(lds, st, lane);
@@ -243,7 +205,6 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     const uint64_t* bmp_t = bmp + (int64_t)kvh * tiles + (int64_t)tb * kTilesPerTb;
     const uint32_t* idx_t = idx + (int64_t)kvh * (tiles + 1) + (int64_t)tb * kTilesPerTb;
     const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
-    unsigned char* lds = smem + wave * kStageBytes;
     const uint32_t chead = (uint32_t)N * (kD / 2);
 
     uint32_t rows = 1u;   // bit n: row n has to be computed
@@ -258,8 +219,8 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
                 float acc[G];
 #pragma unroll
                 for (int h = 0; h < G; h++) acc[h] = 0.f;
-                const uint32_t* qw = reinterpret_cast<const uint32_t*>(q + ((int64_t)bh0 * N + n) * kD);
-                key_tokblk<G>(lds, bmp_t, idx_t, nz_h, qw, chead, lane, acc);
+                const h16x2* qw = reinterpret_cast<const h16x2*>(q + ((int64_t)bh0 * N + n) * kD);
+                key_tokblk<G>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc);
 #pragma unroll
                 for (int h = 0; h < G; h++)
                     out[((int64_t)(bh0 + h) * N + n) * T + (int64_t)tb * 64 + lane] = (h16)acc[h];
@@ -279,13 +240,14 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
 // Accumulate token blocks tb_first, tb_first+4, ... < tb_end of one kv-head: lane = channel,
 // acc0 = channels 0..63, acc1 = channels 64..127, coefficient row `pw` (head stride `chead` words).
 template <int G>
-__device__ __forceinline__ void value_tokblks(unsigned char* lds, const uint64_t* __restrict__ bmp_h,
-                                              const uint32_t* __restrict__ idx_h,
-                                              const unsigned char* __restrict__ nz_h, const uint32_t* __restrict__ pw,
+__device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_off,
+                                              const uint64_t* __restrict__ bmp_h, const uint32_t* __restrict__ idx_h,
+                                              const unsigned char* __restrict__ nz_h, const h16x2* __restrict__ pw,
                                               uint32_t chead, int tb_first, int tb_end, int lane,
                                               float (&acc0)[G], float (&acc1)[G])
 {
     if (tb_first >= tb_end) return;
+    unsigned char* lds = smem + lds_off;
     uint32_t i0 = idx_h[(int64_t)tb_first * kTilesPerTb];
     Stage st;
     {
@@ -309,9 +271,10 @@ __device__ __forceinline__ void value_tokblks(unsigned char* lds, const uint64_t
             }
             __builtin_amdgcn_wave_barrier();
             // chunk c: channel half = c >> 1, tokens (c & 1) * 32 .. +31 of the block
-            const uint32_t* cw = pw + ((uint32_t)tb * 64u + (c & 1) * 32u) / 2u;
-            if (c < 2) chunk32<G>(lds, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, i0, cw, chead, acc0);
-            else       chunk32<G>(lds, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, i0, cw, chead, acc1);
+            const h16x2* cw = pw + ((uint32_t)tb * 64u + (c & 1) * 32u) / 2u;
+            const uint32_t adj = lds_off - 4u * i0;
+            if (c < 2) chunk32<G>(smem, adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cw, chead, acc0);
+            else       chunk32<G>(smem, adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cw, chead, acc1);
             __builtin_amdgcn_wave_barrier();
             if (has_next) {
                 stage_commit(lds, st, lane);
@@ -345,7 +308,6 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
     const uint64_t* bmp_h = bmp + (int64_t)kvh * tiles;
     const uint32_t* idx_h = idx + (int64_t)kvh * (tiles + 1);
     const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
-    unsigned char* lds = smem + wave * kStageBytes;
     float* red = reinterpret_cast<float*>(smem);   // [kWaves][2*G][64], overlays the stage windows
     float* ws_slab = ws + (int64_t)blockIdx.x * BH * N * kD;
     const uint32_t chead = (uint32_t)N * ((uint32_t)T / 2u);
@@ -364,8 +326,9 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
 #pragma unroll
         for (int h = 0; h < G; h++) acc0[h] = acc1[h] = 0.f;
         if (live) {
-            const uint32_t* pw = reinterpret_cast<const uint32_t*>(p + ((int64_t)bh0 * N + n) * T);
-            value_tokblks<G>(lds, bmp_h, idx_h, nz_h, pw, chead, tb0 + wave, tb_end, lane, acc0, acc1);
+            const h16x2* pw = reinterpret_cast<const h16x2*>(p + ((int64_t)bh0 * N + n) * T);
+            value_tokblks<G>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb0 + wave, tb_end, lane, acc0,
+                             acc1);
         }
         __syncthreads();   // every wave is done with its stage window (and with the previous row's sums)
 #pragma unroll
