@@ -1,0 +1,220 @@
+"""Host-side mirror of the attention hook in models/llama_mustafar_kernel.py (LlamaFlashAttention_MUSTAFAR).
+
+The reference file targets transformers 4.43 + flash-attn and cannot be imported here; what this module
+reproduces is the part of `forward` (:199-457) that sits between RoPE and o_proj -- the only part that touches
+the Mustafar operators -- with the same cache tuple, the same trigger rule and the same call sequence:
+
+    prefill (:405-445)  dense causal attention, T = ((L - R)//256)*256, prune+compress [:T], window = the rest
+    decode  (:256-400)  window append, key SpMV, dense window scores, /sqrt(d), fp32 softmax, value SpMV,
+                        dense window p.V, and every 256th step prune+compress the oldest 256 window tokens
+
+`past` is the reference's 6-tuple (k_compressed, k_local_window, v_compressed, v_local_window,
+compressed_length, kv_seq_len) (:445), k_compressed = [bitmaps, idxs, nzs(list per kv-head), nz_offset].
+
+`api="reference"` issues exactly the reference's calls (query/probabilities zero-padded to 8 rows :273/:313,
+`torch.cat` of the per-head streams on every call :274/:314, 8-row outputs sliced to row 0 :275/:315).
+`api="native"` calls the same two entry points un-padded (N = 1) and keeps the packed stream of all heads in
+one flat tensor beside the list, so nothing is re-copied per step.  Both produce the same attention output.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import compression, mustafar_package
+
+
+@dataclass
+class MustafarConfig:
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    k_sparsity: float = 0.7
+    v_sparsity: float = 0.7
+    residual_length: int = 32     # mem_spd_test.py:9, :22
+    group_size: int = 32          # carried by the reference config, unused on the kernel path
+    api: str = "native"           # "reference" | "native"
+
+
+def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:
+    """transformers' repeat_kv as used at model :278, :316."""
+    batch, num_key_value_heads, slen, head_dim = hidden_states.shape
+    if n_rep == 1:
+        return hidden_states
+    hidden_states = hidden_states[:, :, None, :, :].expand(batch, num_key_value_heads, n_rep, slen, head_dim)
+    return hidden_states.reshape(batch, num_key_value_heads * n_rep, slen, head_dim)
+
+
+class FlatStreams(list):
+    """The reference's per-head list of packed-nz tensors, plus the same bytes as ONE flat tensor.
+
+    `torch.cat(streams)` (what the model does on every decode step, :274/:314) still works; `streams.flat` is
+    the zero-copy equivalent used by api="native".
+    """
+
+    def __init__(self, per_head: List[torch.Tensor], flat: Optional[torch.Tensor] = None):
+        super().__init__(per_head)
+        self.flat = flat if flat is not None else (torch.cat(per_head) if len(per_head) else None)
+
+
+def nz_offset_from_idxs(idxs: torch.Tensor, heads: int) -> torch.Tensor:
+    """model :329-331 / :423-425 without the per-head Python loop: nz_offset[i] = sum_{j<i} idxs[j][-1] // 4."""
+    last = idxs.view(heads, -1)[:, -1].to(torch.int64) // 4
+    off = torch.zeros(heads, dtype=torch.int32, device=idxs.device)
+    if heads > 1:
+        off[1:] = torch.cumsum(last, 0)[:-1].to(torch.int32)
+    return off
+
+
+def _compress(x: torch.Tensor, which: str):
+    """x: pruned [B', t, D] -> [bitmaps, idxs, FlatStreams, nz_offset] (model :328-337, :422-434)."""
+    conv = compression.convert_key_batched if which == "key" else compression.convert_value_batched
+    bmps, idxs, nzs = conv(x)
+    return [bmps, idxs, FlatStreams(nzs), nz_offset_from_idxs(idxs, x.shape[0])]
+
+
+def append_compressed(old: list, new: list, heads: int, old_tokens: int, new_tokens: int, head_dim: int) -> list:
+    """Cache append of model :339-368 (K) / :372-390 (V): shift the new offsets by each head's old total, splice
+    bitmaps/offsets per head, concatenate the streams per head, advance nz_offset.  Tensor ops only (the
+    reference builds `last_elements` through a Python list of device scalars, :341)."""
+    o_bmp, o_idx, o_nz, o_off = old
+    n_bmp, n_idx, n_nz, _ = new
+    tiles_per_token = head_dim // 64
+    n_last = n_idx.view(heads, -1)[:, -1].to(torch.int64) // 4                      # :341-342
+    off = o_off.clone()
+    if heads > 1:
+        off[1:] += torch.cumsum(n_last, 0)[:-1].to(torch.int32)                      # :343-344
+    base = o_idx.view(heads, -1)[:, -1:]                                             # :352-353
+    idx = torch.cat([o_idx.view(heads, -1)[:, :-1], n_idx.view(heads, -1) + base], dim=1).flatten()   # :356-360
+    bmp = torch.cat([o_bmp.view(heads, old_tokens * tiles_per_token),
+                     n_bmp.view(heads, new_tokens * tiles_per_token)], dim=1).flatten()               # :364
+    per_head = [torch.cat([o_nz[b], n_nz[b]], dim=0) for b in range(heads)]                           # :368
+    return [bmp, idx, FlatStreams(per_head), off]
+
+
+class MustafarAttention:
+    """Prefill + decode attention over the Mustafar cache (no projections, no RoPE: q/k/v arrive post-RoPE)."""
+
+    def __init__(self, config: MustafarConfig):
+        self.cfg = config
+        self.num_heads = config.num_attention_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        self.head_dim = config.head_dim
+        self.Reduction_Workspace = None   # model :658: a 1-element fp16 tensor shared by all layers
+
+    # ---- pruning (model :77-153) -----------------------------------------------------------------------------
+    def dh_prune_key(self, key_states: torch.Tensor, target_sparsity=None) -> torch.Tensor:
+        return compression.prune_magnitude(key_states, self.cfg.k_sparsity if target_sparsity is None else target_sparsity)
+
+    def dh_prune_value(self, value_states: torch.Tensor, target_sparsity=None) -> torch.Tensor:
+        return compression.prune_magnitude(value_states, self.cfg.v_sparsity if target_sparsity is None else target_sparsity)
+
+    def _ws(self, device):
+        if self.Reduction_Workspace is None or self.Reduction_Workspace.device != device:
+            self.Reduction_Workspace = torch.zeros(1, dtype=torch.float16, device=device)
+        return self.Reduction_Workspace
+
+    # ---- prefill (model :405-445) ----------------------------------------------------------------------------
+    def prefill(self, query_states, key_states, value_states):
+        """q [B,Hq,L,D], k/v [B,Hkv,L,D] fp16 -> (attn_output [B,Hq,L,D], past)."""
+        bsz, _, q_len, D = query_states.shape
+        total_batch_kv = bsz * self.num_key_value_heads
+        kv_seq_len = q_len
+        attn_output = F.scaled_dot_product_attention(                                # flash_attn_func, :410-413
+            query_states, repeat_kv(key_states, self.num_key_value_groups),
+            repeat_kv(value_states, self.num_key_value_groups), is_causal=True)
+        # :416 computes ((L - R)//256)*256, which is -256 for L < R; clamp at 0.
+        compressed_length = max(0, ((kv_seq_len - self.cfg.residual_length) // 256) * 256)
+        if compressed_length != 0:
+            k_pruned = self.dh_prune_key(key_states[:, :, :compressed_length, :])                     # :419
+            v_pruned = self.dh_prune_value(value_states[:, :, :compressed_length, :])                 # :420
+            k_compressed = _compress(k_pruned.reshape(total_batch_kv, -1, D), "key")                  # :422-426
+            k_local_window = key_states[:, :, compressed_length:, :].clone().contiguous()             # :427
+            v_compressed = _compress(v_pruned.reshape(total_batch_kv, -1, D), "value")                # :430-434
+            v_local_window = value_states[:, :, compressed_length:, :].clone().contiguous()           # :435
+        else:
+            k_compressed, k_local_window, v_compressed, v_local_window = None, key_states, None, value_states
+        past = (k_compressed, k_local_window, v_compressed, v_local_window, compressed_length, kv_seq_len)  # :445
+        return attn_output, past
+
+    # ---- decode (model :256-400) -----------------------------------------------------------------------------
+    def decode(self, query_states, key_states, value_states, past, attention_mask=None):
+        """q [B,Hq,1,D], new k/v [B,Hkv,1,D] -> (attn_output [B,Hq,1,D], past)."""
+        cfg = self.cfg
+        bsz, _, q_len, D = query_states.shape
+        total_batch_size = bsz * self.num_heads
+        total_batch_kv = bsz * self.num_key_value_heads
+        groups = self.num_key_value_groups
+        k_compressed, k_local_window, v_compressed, v_local_window, compressed_length, _ = past
+        kv_seq_len = past[-1] + 1                                                                      # :251
+        reference_api = cfg.api == "reference"
+
+        k_local_window = torch.cat([k_local_window, key_states], dim=2)                                # :270
+        if compressed_length != 0:
+            if reference_api:
+                padded_query = F.pad(query_states.view(total_batch_size, -1, D), (0, 0, 0, 7), mode="constant", value=0)   # :273
+                att_compressed = mustafar_package.mustafar_key_formulation(
+                    k_compressed[0], torch.cat(k_compressed[2]), k_compressed[1], k_compressed[3], padded_query,
+                    compressed_length, D, total_batch_size, groups)                                    # :274
+                att_compressed = att_compressed[:, 0:1, :].view(bsz, self.num_heads, 1, compressed_length)   # :275
+            else:
+                att_compressed = mustafar_package.mustafar_key_formulation(
+                    k_compressed[0], k_compressed[2].flat, k_compressed[1], k_compressed[3],
+                    query_states.reshape(total_batch_size, 1, D), compressed_length, D, total_batch_size, groups
+                ).view(bsz, self.num_heads, 1, compressed_length)
+            att_local = torch.matmul(query_states, repeat_kv(k_local_window, groups).transpose(2, 3))  # :278
+            att_qkfull = torch.cat([att_compressed, att_local], dim=-1)                                # :279
+        else:
+            att_qkfull = torch.matmul(query_states, repeat_kv(k_local_window, groups).transpose(2, 3))  # :282
+        attn_weights = att_qkfull / math.sqrt(D)                                                       # :284
+        if attn_weights.size() != (bsz, self.num_heads, q_len, kv_seq_len):
+            raise ValueError(f"Attention weights should be of size {(bsz, self.num_heads, q_len, kv_seq_len)}, "
+                             f"but is {attn_weights.size()}")                                          # :287-291
+        if attention_mask is not None:                                                                 # :293-301
+            attn_weights = attn_weights + attention_mask
+            attn_weights = torch.max(attn_weights, torch.tensor(torch.finfo(attn_weights.dtype).min))
+        attn_weights = F.softmax(attn_weights, dim=-1, dtype=torch.float32).to(query_states.dtype)     # :304
+
+        v_local_window = torch.cat([v_local_window, value_states], dim=2)                              # :309
+        if compressed_length != 0:
+            if reference_api:
+                padded_score = F.pad(attn_weights[:, :, :, :compressed_length].view(total_batch_size, -1, compressed_length),
+                                     (0, 0, 0, 7)).contiguous()                                        # :313
+                out_c = mustafar_package.mustafar_value_formulation(
+                    v_compressed[0], torch.cat(v_compressed[2]), v_compressed[1], v_compressed[3], padded_score,
+                    self._ws(query_states.device), D, compressed_length, total_batch_size, groups)     # :314
+                out_c = out_c[:, 0:1, :].view(bsz, self.num_heads, 1, D)                               # :315
+            else:
+                score = attn_weights[:, :, :, :compressed_length].reshape(total_batch_size, 1, compressed_length)
+                out_c = mustafar_package.mustafar_value_formulation(
+                    v_compressed[0], v_compressed[2].flat, v_compressed[1], v_compressed[3], score,
+                    self._ws(query_states.device), D, compressed_length, total_batch_size, groups
+                ).view(bsz, self.num_heads, 1, D)
+            out_l = torch.matmul(attn_weights[:, :, :, compressed_length:], repeat_kv(v_local_window, groups))   # :316
+            attn_output = out_c + out_l                                                                # :317
+        else:
+            attn_output = torch.matmul(attn_weights, repeat_kv(v_local_window, groups))                # :320
+
+        # :324 (the reference would hand a <256-token window to the compressor when this fires with a short
+        # window, which asserts there; guard instead)
+        if (kv_seq_len - cfg.residual_length - compressed_length) % 256 == 0 and k_local_window.shape[2] >= 256:
+            k_blk = self.dh_prune_key(k_local_window[:, :, :256, :])                                   # :325
+            v_blk = self.dh_prune_value(v_local_window[:, :, :256, :])                                 # :326
+            k_new = _compress(k_blk.reshape(total_batch_kv, -1, D), "key")
+            v_new = _compress(v_blk.reshape(total_batch_kv, -1, D), "value")
+            if compressed_length == 0:                                                                 # :327-337
+                k_compressed, v_compressed = k_new, v_new
+            else:                                                                                      # :339-390
+                k_compressed = append_compressed(k_compressed, k_new, total_batch_kv, compressed_length, 256, D)
+                v_compressed = append_compressed(v_compressed, v_new, total_batch_kv, compressed_length, 256, D)
+            k_local_window = k_local_window[:, :, 256:, :].clone().contiguous()                        # :392
+            v_local_window = v_local_window[:, :, 256:, :].clone().contiguous()                        # :393
+            compressed_length = compressed_length + 256                                                # :398
+
+        past = (k_compressed, k_local_window, v_compressed, v_local_window, compressed_length, kv_seq_len)
+        return attn_output, past

@@ -1,0 +1,83 @@
+"""GPU: the hook mirror (prefill + decode incl. a 256-token compression trigger) against dense attention over the
+pruned-but-dense K/V -- the relationship between the reference's kernel model (llama_mustafar_kernel.py) and its
+dense accuracy model (llama_mustafar_Kt_Mag_Vt_Mag.py:873, :963, :974).  Tolerance: fp16 (rtol 4e-3, atol 2e-3)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dense_reference(q, K_all, V_all, C, ks, vs, groups):
+    """softmax(q K^T / sqrt(d)) V in fp32 with tokens [:C] pruned by the reference rule (CPU oracle)."""
+    K = K_all.clone()
+    V = V_all.clone()
+    if C:
+        K[:, :, :C] = torch.from_numpy(orc.prune_magnitude(K_all[:, :, :C].cpu().numpy(), ks)).to(K.device)
+        V[:, :, :C] = torch.from_numpy(orc.prune_magnitude(V_all[:, :, :C].cpu().numpy(), vs)).to(V.device)
+    Kr = K.float().repeat_interleave(groups, dim=1)
+    Vr = V.float().repeat_interleave(groups, dim=1)
+    s = torch.matmul(q.float(), Kr.transpose(2, 3)) / math.sqrt(q.shape[-1])
+    return torch.matmul(torch.softmax(s, -1), Vr)
+
+
+@pytest.mark.parametrize("api", ["reference", "native"])
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4)])
+def test_prefill_then_decode_matches_dense(api, hq, hkv):
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    torch.manual_seed(42)
+    bsz, D, L0, steps = 2, 128, 300, 262
+    cfg = MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, k_sparsity=0.7, v_sparsity=0.5, api=api)
+    attn = MustafarAttention(cfg)
+    groups = hq // hkv
+    q = torch.randn(bsz, hq, L0, D, device=DEV).half()
+    K_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    V_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    out, past = attn.prefill(q, K_all.clone(), V_all.clone())
+    assert past[4] == 256 and past[5] == L0 and past[1].shape[2] == L0 - 256
+    assert out.shape == (bsz, hq, L0, D)
+    fired = 0
+    for step in range(steps):
+        qn = torch.randn(bsz, hq, 1, D, device=DEV).half()
+        kn = torch.randn(bsz, hkv, 1, D, device=DEV).half()
+        vn = torch.randn(bsz, hkv, 1, D, device=DEV).half()
+        C_before = past[4]
+        K_all = torch.cat([K_all, kn], 2)
+        V_all = torch.cat([V_all, vn], 2)
+        out, past = attn.decode(qn, kn, vn, past)
+        if step % 20 == 0 or past[4] != C_before or step == steps - 1:
+            want = _dense_reference(qn, K_all, V_all, C_before, cfg.k_sparsity, cfg.v_sparsity, groups)
+            torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
+        fired += past[4] != C_before
+        assert past[5] == L0 + step + 1
+        assert past[1].shape[2] == past[5] - past[4]
+    assert fired == 1 and past[4] == 512          # one 256-token trigger crossed (model :324)
+    # cache tuple keeps the reference layout (model :445, :332): [bitmaps, idxs, list-of-streams, nz_offset]
+    kc = past[0]
+    assert kc[0].dtype == torch.int64 and kc[1].dtype == torch.int32 and kc[3].dtype == torch.int32
+    assert isinstance(kc[2], list) and len(kc[2]) == bsz * hkv
+    assert kc[0].numel() == bsz * hkv * 2 * 512 and kc[1].numel() == bsz * hkv * (2 * 512 + 1)
+
+
+def test_decode_without_compressed_part():
+    """compressed_length == 0 branch (model :280-282, :318-320): short prompt stays dense until the first trigger."""
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    torch.manual_seed(1)
+    attn = MustafarAttention(MustafarConfig(num_attention_heads=4, num_key_value_heads=2))
+    q = torch.randn(1, 4, 40, 128, device=DEV).half()
+    k = torch.randn(1, 2, 40, 128, device=DEV).half()
+    v = torch.randn(1, 2, 40, 128, device=DEV).half()
+    _, past = attn.prefill(q, k, v)
+    assert past[0] is None and past[4] == 0
+    K_all, V_all = k, v
+    for _ in range(3):
+        qn, kn, vn = (torch.randn(1, h, 1, 128, device=DEV).half() for h in (4, 2, 2))
+        K_all, V_all = torch.cat([K_all, kn], 2), torch.cat([V_all, vn], 2)
+        out, past = attn.decode(qn, kn, vn, past)
+        want = _dense_reference(qn, K_all, V_all, 0, 0.7, 0.7, 2)
+        torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)

@@ -1,0 +1,121 @@
+"""CPU: host-side logic of the package (no kernels run): C-ABI surface, wrapper argument checks, cache append."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mustafar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t)\s+(\w+)\s*\(", text, flags=re.M)))
+
+
+def test_header_declares_the_reference_entry_points():
+    syms = _declared_symbols()
+    for s in ("Key_SplitK_API", "Value_SplitK_API", "mustafar_prune_magnitude", "mustafar_compress_bitmap_key",
+              "mustafar_compress_bitmap_value", "mustafar_compress_pack_key", "mustafar_compress_pack_value"):
+        assert s in syms
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """The C-ABI library loads here (no GPU) and exports every symbol include/mustafar_hip.h declares."""
+    from mustafar_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run `python __graft_entry__.py` (build) first"
+    L = _lib.load()
+    syms = _declared_symbols()
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} not exported"
+    assert L.mustafar_abi_version() >= 100
+    # pure host helpers (no device access)
+    s = L.mustafar_value_pick_split_k(128, 1, 7936, 256, 4)
+    assert 1 <= s <= 31
+    assert L.mustafar_value_workspace_bytes(128, 1, 7936, 256, 4, 1) == 0
+    assert L.mustafar_value_workspace_bytes(128, 1, 7936, 256, 4, s) >= s * 256 * 128 * 4
+    assert L.mustafar_value_pick_split_k(128, 1, 64, 1, 1) == 1
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    """Shape errors are caught on the host before any launch (MUSTAFAR_EINVAL == 1)."""
+    from mustafar_amd import _lib
+    L = _lib.load()
+    one = ctypes.c_void_p(8)   # never dereferenced: validation fails first
+    assert L.Key_SplitK_API(None, None, one, one, one, one, one, one, 100, 8, 128, None, 1, 4, 1) == 1     # T % 64
+    assert L.Key_SplitK_API(None, None, one, one, one, one, one, one, 128, 8, 64, None, 1, 4, 1) == 1      # head_dim
+    assert L.Key_SplitK_API(None, None, one, one, one, one, one, one, 128, 3, 128, None, 1, 4, 1) == 1     # N
+    assert L.Key_SplitK_API(None, None, one, one, one, one, one, one, 128, 8, 128, None, 1, 6, 4) == 1     # batch % groups
+    assert L.Key_SplitK_API(None, None, None, one, one, one, one, one, 128, 8, 128, None, 1, 4, 1) == 1    # null
+    assert L.Value_SplitK_API(None, None, one, one, one, one, one, one, 64, 8, 128, None, 1, 4, 1) == 1    # M != 128
+    assert L.Value_SplitK_API(None, None, one, one, one, one, one, one, 128, 8, 256, None, 4, 4, 1) == 1   # ws missing
+    assert L.mustafar_prune_magnitude(None, one, one, 4, 64, 10) == 1
+    assert L.mustafar_prune_magnitude(None, one, one, 4, 128, 0) == 1
+    assert L.mustafar_compress_bitmap_key(None, one, 2, 100, 128, one, one, one) == 1
+
+
+def test_wrapper_checks_match_reference_messages():
+    """mustafar_wrapper.cu:36-73: dtype/device errors are RuntimeErrors with the reference's messages."""
+    from mustafar_amd import mustafar_package as mp
+    bmp = torch.zeros(4, dtype=torch.int64)
+    nz = torch.zeros(8, dtype=torch.float16)
+    idx = torch.zeros(5, dtype=torch.int32)
+    off = torch.zeros(1, dtype=torch.int32)
+    B = torch.zeros((1, 8, 128), dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="Tensor B must be of type float16"):
+        mp.mustafar_key_formulation(bmp, nz, idx, off, B.float(), 64, 128, 1, 1)
+    with pytest.raises(RuntimeError, match="Tensor NZ must be of type float16"):
+        mp.mustafar_key_formulation(bmp, nz.float(), idx, off, B, 64, 128, 1, 1)
+    with pytest.raises(RuntimeError, match="Tensor bmp must be of type int64"):
+        mp.mustafar_key_formulation(bmp.int(), nz, idx, off, B, 64, 128, 1, 1)
+    with pytest.raises(RuntimeError, match="Tensor idx must be of type int"):
+        mp.mustafar_value_formulation(bmp, nz, idx.long(), off, B, nz, 128, 64, 1, 1)
+    with pytest.raises(RuntimeError, match="Tensor NZ_Offset must be of type int"):
+        mp.mustafar_value_formulation(bmp, nz, idx, off.long(), B, nz, 128, 64, 1, 1)
+    with pytest.raises(RuntimeError, match="must be on CUDA device"):   # all CPU: the reference's TORCH_CHECK (:70-73)
+        mp.mustafar_key_formulation(bmp, nz, idx, off, B, 64, 128, 1, 1)
+
+
+def test_kth_matches_reference_expression():
+    from mustafar_amd.compression import kth_from_sparsity
+    for s, want in ((0.5, 64), (0.7, 89), (0.8, 102), (0.0, 1), (0.99, 126), (0.3, 38)):
+        assert kth_from_sparsity(s, 128) == want == orc.kth_from_sparsity(s, 128)
+
+
+@pytest.mark.parametrize("which", ["key", "value"])
+def test_cache_append_equals_one_shot_compression(which):
+    """Property of the format + hook append (model :339-390): compress(A) ++ compress(B) == compress(A||B)."""
+    from mustafar_amd.hook import FlatStreams, append_compressed, nz_offset_from_idxs
+    rng = np.random.default_rng(0)
+    heads, D = 3, 128
+    x = orc.prune_magnitude(rng.standard_normal((heads, 768, D)).astype(np.float16), 0.7)
+    conv = orc.convert_key_batched if which == "key" else orc.convert_value_batched
+
+    def pack(xs):
+        bmp, accum, nzs = conv(xs)
+        idxs = torch.from_numpy(accum)
+        return [torch.from_numpy(bmp), idxs, FlatStreams([torch.from_numpy(n) for n in nzs]), nz_offset_from_idxs(idxs, heads)]
+
+    cache = pack(x[:, :256])
+    cache = append_compressed(cache, pack(x[:, 256:512]), heads, 256, 256, D)
+    cache = append_compressed(cache, pack(x[:, 512:768]), heads, 512, 256, D)
+    want = pack(x)
+    assert torch.equal(cache[0].view(heads, -1), want[0])
+    assert torch.equal(cache[1].view(heads, -1), want[1])
+    assert torch.equal(cache[3], want[3])
+    assert torch.equal(torch.cat(cache[2]).view(torch.int16), torch.cat(want[2]).view(torch.int16))
+    assert torch.equal(cache[2].flat.view(torch.int16), want[2].flat.view(torch.int16))
+    assert np.array_equal(cache[3].numpy(), orc.nz_offset_from_idx(want[1].numpy()))
+    # the appended cache drives the oracle SpMV to the same scores as the one-shot cache
+    q = rng.standard_normal((heads, 1, D)).astype(np.float16)
+    if which == "key":
+        a, _ = orc.key_spmv(cache[0].numpy(), cache[2].flat.numpy(), cache[1].numpy(), cache[3].numpy(), q, 768, D, heads, 1)
+        b, _ = orc.key_spmv(want[0].numpy(), want[2].flat.numpy(), want[1].numpy(), want[3].numpy(), q, 768, D, heads, 1)
+        assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
