@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- decode-step throughput of the Mustafar sparse-attention path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--layers 32]
+
+One "step" = one decode step of the attention path over all layers (32): per layer the key SpMV over the
+compressed cache, the dense window scores, scale + fp32 softmax, the value SpMV, the dense window p.V
+(SURVEY 8d).  Inputs are synthetic N(0,1) K/V/q at the model geometry (no weights exist offline), pruned with the
+reference rule and compressed by the HIP kernels; everything is resident in HBM before the timed region.
+
+Workloads: c2 Llama-2-7B 70% L=4096 b1 | c3 Llama-3-8B 70% L=8192 b8 (default: the config the
+metric is quoted on) | c4 Llama-3-8B 80% L=32768 b4 | c5 Mistral-7B 70% L=16384 b16 | c1 plumbing.
+
+Multi-GPU: the path does not shard one sequence (north_star) -> independent replicas, one process per GPU,
+no data-path collective; `value` = units of all ranks / max-over-ranks time ("scaling": "weak").
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {  # name: (label, Hq, Hkv, sparsity, L, batch)
+    "c1": ("Llama-2-7B 50% L=1024 b1 (plumbing)", 32, 32, 0.5, 1024, 1),
+    "c2": ("Llama-2-7B 70% L=4096 b1", 32, 32, 0.7, 4096, 1),
+    "c3": ("Llama-3-8B 70% L=8192 b8", 32, 8, 0.7, 8192, 8),
+    "c4": ("Llama-3-8B 80% L=32768 b4", 32, 8, 0.8, 32768, 4),
+    "c5": ("Mistral-7B 70% L=16384 b16", 32, 8, 0.7, 16384, 16),
+}
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-api", action="store_true", help="skip the second timing with the reference call sequence")
+    return ap.parse_args()
+
+
+def cache_bytes(past):
+    k_c, k_w, v_c, v_w, _, _ = past
+    n = k_w.numel() * 2 + v_w.numel() * 2
+    for c in (k_c, v_c):
+        if c is not None:
+            n += c[0].numel() * 8 + c[1].numel() * 4 + c[2].flat.numel() * 2 + c[3].numel() * 4
+    return n
+
+
+def algorithmic_bytes(past, BH, which):
+    """compressed bytes once per kv-head + dense operand in + result out, per launch."""
+    c = past[0] if which == "key" else past[2]
+    T = past[4]
+    return c[0].numel() * 8 + c[1].numel() * 4 + c[2].flat.numel() * 2 + BH * 128 * 2 + BH * T * 2
+
+
+class KernelTimer:
+    """HIP events around every call of the two operators, recorded on torch's current stream -- the stream the
+    C ABI launches on."""
+
+    def __init__(self, mp):
+        self.mp = mp
+        self.orig = (mp.mustafar_key_formulation, mp.mustafar_value_formulation)
+        self.events = {"key": [], "value": []}
+        self.enabled = False
+
+    def install(self):
+        def wrap(fn, name):
+            def inner(*a, **kw):
+                if not self.enabled:
+                    return fn(*a, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*a, **kw)
+                e1.record()
+                self.events[name].append((e0, e1))
+                return out
+            return inner
+        self.mp.mustafar_key_formulation = wrap(self.orig[0], "key")
+        self.mp.mustafar_value_formulation = wrap(self.orig[1], "value")
+
+    def reset(self):
+        self.events = {"key": [], "value": []}
+
+    def avg_us(self, name):
+        ev = self.events[name]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)) * 1e3, len(ev)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist   # RCCL; used only for the barrier and the max-over-ranks of the time
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mustafar_amd import mustafar_package as mp
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+
+    label, Hq, Hkv, s, L, batch = CONFIGS[a.config]
+    D, R = 128, 32
+    T = ((L - R) // 256) * 256
+    BH = batch * Hq
+    torch.manual_seed(42 + rank)                       # seed of mem_spd_test.py:63 (+rank: replicas differ)
+    cfg = MustafarConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, k_sparsity=s, v_sparsity=s,
+                         residual_length=R, api="native")
+    attn = MustafarAttention(cfg)
+    timer = KernelTimer(mp)
+    timer.install()
+
+    # ---- build the per-layer caches (resident before the timed region) ------------------------------------------
+    torch.cuda.reset_peak_memory_stats(dev)
+    pasts, qs, ks, vs = [], [], [], []
+    for _ in range(a.layers):
+        K = torch.randn(batch, Hkv, L, D, device=dev, dtype=torch.float32).half()
+        V = torch.randn(batch, Hkv, L, D, device=dev, dtype=torch.float32).half()
+        pasts.append(attn.build_cache(K, V))
+        del K, V
+        qs.append(torch.randn(batch, Hq, 1, D, device=dev).half())
+        ks.append(torch.randn(batch, Hkv, 1, D, device=dev).half())
+        vs.append(torch.randn(batch, Hkv, 1, D, device=dev).half())
+    kv_bytes = sum(cache_bytes(p) for p in pasts)
+    dense_bytes = a.layers * 2 * batch * Hkv * L * D * 2
+    alg_key = algorithmic_bytes(pasts[0], BH, "key")
+    alg_val = algorithmic_bytes(pasts[0], BH, "value")
+    alg_key_all = sum(algorithmic_bytes(p, BH, "key") for p in pasts) / a.layers
+    alg_val_all = sum(algorithmic_bytes(p, BH, "value") for p in pasts) / a.layers
+
+    def one_step(state):
+        for l in range(a.layers):
+            _, state[l] = attn.decode(qs[l], ks[l], vs[l], state[l])
+
+    def timed(api, steps, warmup):
+        cfg.api = api
+        state = list(pasts)                    # decode() never mutates a past in place: the base caches stay intact
+        for _ in range(warmup):
+            one_step(state)
+        timer.reset()
+        timer.enabled = True
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step(state)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed("native", a.steps, a.warmup)
+    key_us, n_key = timer.avg_us("key")
+    val_us, n_val = timer.avg_us("value")
+    ref = None
+    if not a.no_reference_api:
+        dt_ref = timed("reference", max(2, a.steps // 2), 1)
+        ref = {"value": world * batch * max(2, a.steps // 2) / dt_ref, "unit": "tokens/s",
+               "ms_per_step": dt_ref / max(2, a.steps // 2) * 1e3,
+               "key_call_us": round(timer.avg_us("key")[0], 2), "value_call_us": round(timer.avg_us("value")[0], 2),
+               "note": "exact reference call sequence: q/p zero-padded to 8 rows, torch.cat of per-head streams per call, 8-row outputs"}
+    alloc_peak = torch.cuda.max_memory_allocated(dev)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (HIP events recorded live in the timed region above) ------------------
+    dom = "value" if val_us >= key_us else "key"
+    dom_us = max(val_us, key_us)
+    dom_bytes = alg_val_all if dom == "value" else alg_key_all
+    achieved = dom_bytes / (dom_us * 1e-6) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, measured offline
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(a.config, {}).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": f"{dom}_spmv_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_timed": n_val if dom == "value" else n_key,
+                "other": {"kernel": ("key" if dom == "value" else "value") + "_spmv_kernel",
+                          "avg_launch_us": round(min(val_us, key_us), 2),
+                          "achieved": round((alg_key_all if dom == "value" else alg_val_all) / (min(val_us, key_us) * 1e-6) / 1e9, 1)},
+                "frac_of_measured_stream_ceiling_6290": round(achieved / 6290.0, 4)}
+
+    # ---- host-CPU dense baseline (oracle/dense_ref.py: the reference's dense pruned path), bounded sample --------
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        from oracle.dense_ref import time_dense_cpu
+        keep = 1.0 - (max(1, int(s * D)) - 1) / D
+        sample_layers = 1
+        t_layer, how, reps = time_dense_cpu(batch, Hq, Hkv, L, D, keep, layers_sample=sample_layers, repeats=3)
+        cpu = {"value": round(batch / (t_layer * a.layers), 4), "unit": "tokens/s", "cores": torch.get_num_threads(),
+               "kind": "port",
+               "sample": f"{sample_layers} of {a.layers} layers of the same workload ({label}), dense pruned q.K^T/sqrt(d) -> fp32 softmax -> p.V "
+                         f"in PyTorch on the host ({how}), median of {reps} runs after a probe, scaled x{a.layers}/{sample_layers}"}
+
+    out = {
+        "metric": "decode_tokens_per_sec", "value": round(world * batch * a.steps / dt, 2), "unit": "tokens/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": label, "id": a.config, "layers": a.layers, "q_heads": Hq, "kv_heads": Hkv, "head_dim": D,
+                   "sparsity": s, "seq_len": L, "compressed_tokens": T, "batch_per_gpu": batch, "residual_length": R,
+                   "api": "mustafar_package entry points, un-padded (N=1) operands", "parallelism": f"replicas x{world}"},
+        "peak_kv_bytes": int(kv_bytes), "dense_kv_bytes": int(dense_bytes), "kv_compression_ratio": round(dense_bytes / kv_bytes, 3),
+        "allocator_peak_bytes": int(alloc_peak),
+        "roofline": roofline, "cpu_baseline": cpu, "reference_call_sequence": ref,
+    }
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

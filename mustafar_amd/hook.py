@@ -120,14 +120,10 @@ class MustafarAttention:
         return self.Reduction_Workspace
 
     # ---- prefill (model :405-445) ----------------------------------------------------------------------------
-    def prefill(self, query_states, key_states, value_states):
-        """q [B,Hq,L,D], k/v [B,Hkv,L,D] fp16 -> (attn_output [B,Hq,L,D], past)."""
-        bsz, _, q_len, D = query_states.shape
+    def build_cache(self, key_states, value_states):
+        """The cache-construction half of prefill (model :416-445): k/v [B,Hkv,L,D] fp16 -> past."""
+        bsz, _, kv_seq_len, D = key_states.shape
         total_batch_kv = bsz * self.num_key_value_heads
-        kv_seq_len = q_len
-        attn_output = F.scaled_dot_product_attention(                                # flash_attn_func, :410-413
-            query_states, repeat_kv(key_states, self.num_key_value_groups),
-            repeat_kv(value_states, self.num_key_value_groups), is_causal=True)
         # :416 computes ((L - R)//256)*256, which is -256 for L < R (SURVEY 3.3 quirk); clamp at 0.
         compressed_length = max(0, ((kv_seq_len - self.cfg.residual_length) // 256) * 256)
         if compressed_length != 0:
@@ -139,8 +135,14 @@ class MustafarAttention:
             v_local_window = value_states[:, :, compressed_length:, :].clone().contiguous()           # :435
         else:
             k_compressed, k_local_window, v_compressed, v_local_window = None, key_states, None, value_states
-        past = (k_compressed, k_local_window, v_compressed, v_local_window, compressed_length, kv_seq_len)  # :445
-        return attn_output, past
+        return (k_compressed, k_local_window, v_compressed, v_local_window, compressed_length, kv_seq_len)   # :445
+
+    def prefill(self, query_states, key_states, value_states):
+        """q [B,Hq,L,D], k/v [B,Hkv,L,D] fp16 -> (attn_output [B,Hq,L,D], past)."""
+        attn_output = F.scaled_dot_product_attention(                                # flash_attn_func, :410-413
+            query_states, repeat_kv(key_states, self.num_key_value_groups),
+            repeat_kv(value_states, self.num_key_value_groups), is_causal=True)
+        return attn_output, self.build_cache(key_states, value_states)
 
     # ---- decode (model :256-400) -----------------------------------------------------------------------------
     def decode(self, query_states, key_states, value_states, past, attention_mask=None):
