@@ -76,55 +76,173 @@ __device__ __forceinline__ void stage_commit(unsigned char* lds, const Stage& s,
 
 typedef h16 h16x2 __attribute__((ext_vector_type(2)));
 
-// Tiles are processed kStep at a time inside a REAL (not unrolled) loop.  Fully unrolled, the compiler
-// floats every scalar bitmap load of a token block to the top of the basic block (invariant loads carry
-// no ordering edge) and spills hundreds of SGPRs through v_writelane.  Latency of the scalar loads and of
-// the LDS gathers is covered by occupancy (7-8 waves per SIMD), not by software pipelining: SMEM and LDS
-// share lgkmcnt and SMEM returns out of order, so every step drains the counter anyway.
-constexpr int kStep = 8;
+// ---------------------------------------------------------------------------------------------------------
+// Inner loop: hand-written for gfx950.  Measured issue rates on MI355X (tools/ubench/issue_rates.hip):
+// v_mbcnt / v_lshl_add / v_cndmask / v_fma_mix / anything with an SGPR operand issue at ~1 wave-instruction
+// per cycle per CU, SALU at ~1 per cycle per CU beside them.  At ~118 B of traffic per tile the HBM roofline
+// leaves ~3 CU-cycles per tile, so the loop is written to the instruction, 8 tiles ("step") at a time:
+//
+//   VALU per tile : v_mbcnt_lo, v_mbcnt_hi (rank of the lane's element in the packed stream),
+//                   v_lshl_add_u32 (LDS address), G x v_fma_mix_f32 (fp16 x fp16 -> fp32 accumulate, the
+//                   coefficient is an SGPR half picked by op_sel)                                   = 3 + G
+//   no mask op    : the FMAs run under EXEC = bit-reversed bitmap (one s_mov_b64 per tile), so lanes whose
+//                   element is zero neither need a v_cndmask nor a clean gather result
+//   SALU per tile : s_brev_b64, s_lshl2_add_u32 (tile's LDS byte offset), s_mov_b64 exec            = 3
+//   per step      : 2 + G scalar loads (bitmaps x16, offsets x8, coefficients x4 per head) for the NEXT step,
+//                   issued between the gather wait and the FMAs; two s_waitcnt lgkmcnt(0) (SMEM returns out
+//                   of order and shares the counter with the LDS gathers, so every wait is a full drain).
+//
+// Every lgkm-counted operation of the loop (s_load, ds_read) lives inside asm statements so that the
+// compiler's own counted waits never see a queue it does not know about; the chunk staging around it uses
+// vmcnt (buffer loads) and LDS stores only.
 
-//   smem    : base of the workgroup's LDS; `adj` = (this wave's window offset) - 4 * idx0, where idx0 is the
-//             stream offset (half2 units) of the first byte held in the window  -> tile offset = 4*idx + adj
-//   bmp/idx : wave-uniform pointers to the chunk's 32 bitmaps / stream offsets (scalar loads)
-//   cw      : coefficient pairs (2 halfs) of head 0 for the chunk's tiles; head stride `chead` (pairs)
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
 template <int G>
-__device__ __forceinline__ void chunk32(const unsigned char* smem, uint32_t adj, const uint64_t* __restrict__ bmp,
-                                        const uint32_t* __restrict__ idx, const h16x2* __restrict__ cw,
-                                        uint32_t chead, float (&acc)[G])
+struct Meta {          // scalar operands of one step (8 tiles) -- all SGPRs
+    u32x16 bm;         // 8 bitmaps (lo, hi dwords)
+    u32x8 ix;          // 8 stream offsets (half2 units)
+    u32x4 c[G];        // per head: 8 coefficients (4 dwords of 2 halfs)
+};
+
+// Issue the scalar loads of step S of a chunk (byte offsets are immediates).  Nothing may read `m` before a
+// meta_wait() that follows.
+template <int G, int S>
+__device__ __forceinline__ void meta_issue(Meta<G>& m, const uint64_t* __restrict__ bmp,
+                                           const uint32_t* __restrict__ idx, const h16x2* const (&cp)[G])
 {
-#pragma unroll 1
-    for (int s = 0; s < kChunkTiles / kStep; s++) {
-        uint64_t rb[kStep];    // bit-reversed bitmaps: bit i <=> element i (the format is MSB-first) -- SGPR pairs
-        uint32_t off[kStep];   // byte offset of each tile's stream in LDS                           -- SGPRs
-#pragma unroll
-        for (int j = 0; j < kStep; j++) {
-            rb[j]  = __builtin_bitreverse64(bmp[s * kStep + j]);
-            off[j] = idx[s * kStep + j] * 4u + adj;
-        }
-        h16x2 c[G][kStep / 2];
-#pragma unroll
-        for (int h = 0; h < G; h++)
-#pragma unroll
-            for (int jj = 0; jj < kStep / 2; jj++) c[h][jj] = cw[h * chead + s * (kStep / 2) + jj];
-        uint32_t v[kStep];
-#pragma unroll
-        for (int j = 0; j < kStep; j++) {
-            // rank of this lane's element among the tile's non-zeros = set bits below the lane
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rb[j] >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)rb[j], 0u));
-            v[j] = *reinterpret_cast<const uint16_t*>(smem + ((rank << 1) + off[j]));
-        }
-#pragma unroll
-        for (int j = 0; j < kStep; j++) {
-            const bool on = __builtin_amdgcn_inverse_ballot_w64(rb[j]);   // SGPR pair used directly as lane mask
-            const h16 x = __builtin_bit_cast(h16, on ? (uint16_t)v[j] : (uint16_t)0);
-#pragma unroll
-            for (int h = 0; h < G; h++) {
-                const h16 cc = (j & 1) ? c[h][j / 2].y : c[h][j / 2].x;   // op_sel of v_fma_mix_f32 on an SGPR
-                acc[h] = __builtin_fmaf((float)x, (float)cc, acc[h]);
-            }
-        }
+    if constexpr (G == 4) {
+        asm volatile("s_load_dwordx16 %0, %6, %10\n\ts_load_dwordx8 %1, %7, %11\n\t"
+                     "s_load_dwordx4 %2, %8, %12\n\ts_load_dwordx4 %3, %9, %12\n\t"
+                     "s_load_dwordx4 %4, %13, %12\n\ts_load_dwordx4 %5, %14, %12"
+                     : "=&s"(m.bm), "=&s"(m.ix), "=&s"(m.c[0]), "=&s"(m.c[1]), "=&s"(m.c[2]), "=&s"(m.c[3])
+                     : "s"(bmp), "s"(idx), "s"(cp[0]), "s"(cp[1]), "i"(S * 64), "i"(S * 32), "i"(S * 16), "s"(cp[2]), "s"(cp[3]));
+    } else if constexpr (G == 2) {
+        asm volatile("s_load_dwordx16 %0, %4, %8\n\ts_load_dwordx8 %1, %5, %9\n\t"
+                     "s_load_dwordx4 %2, %6, %10\n\ts_load_dwordx4 %3, %7, %10"
+                     : "=&s"(m.bm), "=&s"(m.ix), "=&s"(m.c[0]), "=&s"(m.c[1])
+                     : "s"(bmp), "s"(idx), "s"(cp[0]), "s"(cp[1]), "i"(S * 64), "i"(S * 32), "i"(S * 16));
+    } else {
+        asm volatile("s_load_dwordx16 %0, %3, %6\n\ts_load_dwordx8 %1, %4, %7\n\ts_load_dwordx4 %2, %5, %8"
+                     : "=&s"(m.bm), "=&s"(m.ix), "=&s"(m.c[0])
+                     : "s"(bmp), "s"(idx), "s"(cp[0]), "i"(S * 64), "i"(S * 32), "i"(S * 16));
     }
+}
+
+// Drain the counter; the compiler may read `m` only after this statement.
+template <int G>
+__device__ __forceinline__ void meta_wait(Meta<G>& m)
+{
+    if constexpr (G == 4)      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]), "+s"(m.c[1]), "+s"(m.c[2]), "+s"(m.c[3]));
+    else if constexpr (G == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]), "+s"(m.c[1]));
+    else                       asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]));
+}
+
+struct Gathered {
+    uint64_t m[8];   // bit i <=> element i of the tile non-zero (SGPR pairs; the format stores element i at bit 63 - i)
+    uint32_t t[8];   // gathered halfs (VGPRs; meaningful only in lanes whose bit is set, and only after gather_wait)
+};
+
+#define MUSTAFAR_GATHER(j)                                                  \
+    "s_lshl2_add_u32 %[o" #j "], %[o" #j "], %[adj]\n\t"                     \
+    "v_mbcnt_lo_u32_b32 %[t" #j "], %[l" #j "], 0\n\t"                        \
+    "v_mbcnt_hi_u32_b32 %[t" #j "], %[h" #j "], %[t" #j "]\n\t"               \
+    "v_lshl_add_u32 %[t" #j "], %[t" #j "], 1, %[o" #j "]\n\t"                \
+    "ds_read_u16 %[t" #j "], %[t" #j "]\n\t"
+#define MUSTAFAR_GOPS(j) [l##j] "s"((uint32_t)g.m[j]), [h##j] "s"((uint32_t)(g.m[j] >> 32))
+
+// Gather the 8 tiles of a step from the wave's LDS window (no wait).
+//   adj = (LDS byte address of the window) - 4 * (stream offset of its first byte)  ->  tile offset = 4*idx + adj
+template <int G>
+__device__ __forceinline__ void gather8(const Meta<G>& m, uint32_t adj, Gathered& g)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) g.m[j] = __builtin_bitreverse64(m.bm[2 * j] | ((uint64_t)m.bm[2 * j + 1] << 32));
+    uint32_t o0 = m.ix[0], o1 = m.ix[1], o2 = m.ix[2], o3 = m.ix[3], o4 = m.ix[4], o5 = m.ix[5], o6 = m.ix[6], o7 = m.ix[7];
+    asm volatile(MUSTAFAR_GATHER(0) MUSTAFAR_GATHER(1) MUSTAFAR_GATHER(2) MUSTAFAR_GATHER(3)
+                 MUSTAFAR_GATHER(4) MUSTAFAR_GATHER(5) MUSTAFAR_GATHER(6) MUSTAFAR_GATHER(7)
+                 : [t0] "=&v"(g.t[0]), [t1] "=&v"(g.t[1]), [t2] "=&v"(g.t[2]), [t3] "=&v"(g.t[3]), [t4] "=&v"(g.t[4]),
+                   [t5] "=&v"(g.t[5]), [t6] "=&v"(g.t[6]), [t7] "=&v"(g.t[7]), [o0] "+s"(o0), [o1] "+s"(o1), [o2] "+s"(o2),
+                   [o3] "+s"(o3), [o4] "+s"(o4), [o5] "+s"(o5), [o6] "+s"(o6), [o7] "+s"(o7)
+                 : MUSTAFAR_GOPS(0), MUSTAFAR_GOPS(1), MUSTAFAR_GOPS(2), MUSTAFAR_GOPS(3), MUSTAFAR_GOPS(4), MUSTAFAR_GOPS(5),
+                   MUSTAFAR_GOPS(6), MUSTAFAR_GOPS(7), [adj] "s"(adj)
+                 : "scc");
+}
+
+__device__ __forceinline__ void gather_wait(Gathered& g)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]), "+v"(g.t[7]));
+}
+
+#define MUSTAFAR_FMA(a, j, c, sel) "v_fma_mix_f32 %[" #a "], %[t" #j "], %[" #c "], %[" #a "] " sel "\n\t"
+#define MUSTAFAR_LO "op_sel_hi:[1,1,0]"
+#define MUSTAFAR_HI "op_sel:[0,1,0] op_sel_hi:[1,1,0]"
+#define MUSTAFAR_FMA4(j, w, sel)                                                                     \
+    "s_mov_b64 exec, %[m" #j "]\n\t" MUSTAFAR_FMA(a0, j, c0##w, sel) MUSTAFAR_FMA(a1, j, c1##w, sel)   \
+    MUSTAFAR_FMA(a2, j, c2##w, sel) MUSTAFAR_FMA(a3, j, c3##w, sel)
+#define MUSTAFAR_FMA2(j, w, sel) \
+    "s_mov_b64 exec, %[m" #j "]\n\t" MUSTAFAR_FMA(a0, j, c0##w, sel) MUSTAFAR_FMA(a1, j, c1##w, sel)
+#define MUSTAFAR_FMA1(j, w, sel) "s_mov_b64 exec, %[m" #j "]\n\t" MUSTAFAR_FMA(a0, j, c0##w, sel)
+#define MUSTAFAR_FOPS                                                                                              \
+    [m0] "s"(g.m[0]), [m1] "s"(g.m[1]), [m2] "s"(g.m[2]), [m3] "s"(g.m[3]), [m4] "s"(g.m[4]), [m5] "s"(g.m[5]),      \
+    [m6] "s"(g.m[6]), [m7] "s"(g.m[7]), [t0] "v"(g.t[0]), [t1] "v"(g.t[1]), [t2] "v"(g.t[2]), [t3] "v"(g.t[3]),      \
+    [t4] "v"(g.t[4]), [t5] "v"(g.t[5]), [t6] "v"(g.t[6]), [t7] "v"(g.t[7])
+#define MUSTAFAR_COPS(h) [c##h##0] "s"(m.c[h][0]), [c##h##1] "s"(m.c[h][1]), [c##h##2] "s"(m.c[h][2]), [c##h##3] "s"(m.c[h][3])
+
+// acc[h] += tile element x coefficient for the 8 gathered tiles.  The FMAs of tile j run under EXEC = its
+// bitmap, so lanes whose element is zero are untouched: no v_cndmask and no clean gather result needed.
+template <int G>
+__device__ __forceinline__ void fma8(const Meta<G>& m, const Gathered& g, float (&acc)[G])
+{
+    if constexpr (G == 4) {
+        asm volatile(MUSTAFAR_FMA4(0, 0, MUSTAFAR_LO) MUSTAFAR_FMA4(1, 0, MUSTAFAR_HI) MUSTAFAR_FMA4(2, 1, MUSTAFAR_LO)
+                     MUSTAFAR_FMA4(3, 1, MUSTAFAR_HI) MUSTAFAR_FMA4(4, 2, MUSTAFAR_LO) MUSTAFAR_FMA4(5, 2, MUSTAFAR_HI)
+                     MUSTAFAR_FMA4(6, 3, MUSTAFAR_LO) MUSTAFAR_FMA4(7, 3, MUSTAFAR_HI) "s_mov_b64 exec, -1"
+                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+                     : MUSTAFAR_FOPS, MUSTAFAR_COPS(0), MUSTAFAR_COPS(1), MUSTAFAR_COPS(2), MUSTAFAR_COPS(3));
+    } else if constexpr (G == 2) {
+        asm volatile(MUSTAFAR_FMA2(0, 0, MUSTAFAR_LO) MUSTAFAR_FMA2(1, 0, MUSTAFAR_HI) MUSTAFAR_FMA2(2, 1, MUSTAFAR_LO)
+                     MUSTAFAR_FMA2(3, 1, MUSTAFAR_HI) MUSTAFAR_FMA2(4, 2, MUSTAFAR_LO) MUSTAFAR_FMA2(5, 2, MUSTAFAR_HI)
+                     MUSTAFAR_FMA2(6, 3, MUSTAFAR_LO) MUSTAFAR_FMA2(7, 3, MUSTAFAR_HI) "s_mov_b64 exec, -1"
+                     : [a0] "+v"(acc[0]), [a1] "+v"(acc[1])
+                     : MUSTAFAR_FOPS, MUSTAFAR_COPS(0), MUSTAFAR_COPS(1));
+    } else {
+        asm volatile(MUSTAFAR_FMA1(0, 0, MUSTAFAR_LO) MUSTAFAR_FMA1(1, 0, MUSTAFAR_HI) MUSTAFAR_FMA1(2, 1, MUSTAFAR_LO)
+                     MUSTAFAR_FMA1(3, 1, MUSTAFAR_HI) MUSTAFAR_FMA1(4, 2, MUSTAFAR_LO) MUSTAFAR_FMA1(5, 2, MUSTAFAR_HI)
+                     MUSTAFAR_FMA1(6, 3, MUSTAFAR_LO) MUSTAFAR_FMA1(7, 3, MUSTAFAR_HI) "s_mov_b64 exec, -1"
+                     : [a0] "+v"(acc[0])
+                     : MUSTAFAR_FOPS, MUSTAFAR_COPS(0));
+    }
+}
+
+// One staged chunk = 32 tiles = 4 steps of 8.  Per step:
+//   gather(s) -> wait (LDS latency of the last gather) -> issue scalar loads(s+1) -> FMAs(s) -> wait (what is
+//   left of the scalar-load latency) -> gather(s+1) ...
+// i.e. the scalar loads get the whole FMA phase (the only stretch without a wait) to land.
+//   bmp/idx : wave-uniform pointers to the chunk's 32 bitmaps / stream offsets
+//   cp[h]   : coefficient pairs of head h for the chunk's first tile (32 consecutive halfs are used)
+template <int G>
+__device__ __forceinline__ void chunk32(uint32_t adj, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx,
+                                        const h16x2* const (&cp)[G], float (&acc)[G])
+{
+    Meta<G> cur, nxt;
+    Gathered g;
+    meta_issue<G, 0>(cur, bmp, idx, cp);
+    meta_wait<G>(cur);
+#define MUSTAFAR_STEP(S)                        \
+    gather8<G>(cur, adj, g);                    \
+    gather_wait(g);                             \
+    meta_issue<G, S + 1>(nxt, bmp, idx, cp);    \
+    fma8<G>(cur, g, acc);                       \
+    meta_wait<G>(nxt);                          \
+    cur = nxt;
+    MUSTAFAR_STEP(0) MUSTAFAR_STEP(1) MUSTAFAR_STEP(2)
+#undef MUSTAFAR_STEP
+    gather8<G>(cur, adj, g);
+    gather_wait(g);
+    fma8<G>(cur, g, acc);
 }
 
 __device__ __forceinline__ uint32_t nzbits(uint4 v)
@@ -156,7 +274,35 @@ __device__ __forceinline__ uint32_t pad_row_mask(const h16* __restrict__ dense, 
 }
 
 // ------------------------------------------------------------------------------------------------ key
-// One 64-token block against coefficient row `qw` (head stride `chead` words) -> acc[h] for lane = token.
+// The 5 stream offsets that bound the 4 chunks of a 64-token block (idx[0], idx[32], ..., idx[128]), fetched by
+// lanes 0..4 with one vector load; bnd_get() broadcasts one of them into an SGPR (v_readlane).
+__device__ __forceinline__ uint32_t bnd_load(const uint32_t* __restrict__ idx_t, int lane)
+{
+    return idx_t[(lane < 5 ? lane : 0) * kChunkTiles];
+}
+__device__ __forceinline__ uint32_t bnd_get(uint32_t bnd, int k) { return __builtin_amdgcn_readlane(bnd, k); }
+
+// Pull the metadata lines of one 64-token block (16 x 64 B of bitmaps, 9 of offsets) and, for the value kernel,
+// its coefficient lines (2 x 64 B of probabilities per head) into L2 with ONE vector load, 4 bytes per line.
+// The scalar loads of the inner loop then hit L2 instead of paying an HBM miss every other half-step (the
+// scalar path has no prefetch of its own and every wait on it is a full drain).  The value is never used.
+template <int NCOEF>
+__device__ __forceinline__ uint32_t prefetch_meta(const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
+                                                  const h16x2* __restrict__ coef, uint32_t chead, int lane)
+{
+    const unsigned char* a = reinterpret_cast<const unsigned char*>(bmp_t) + lane * 64;
+    if (lane >= 16) a = reinterpret_cast<const unsigned char*>(idx_t) + (lane - 16) * 64;
+    if (NCOEF > 0 && lane >= 25) {
+        const int k = lane - 25;   // head k / 2, line k % 2
+        a = reinterpret_cast<const unsigned char*>(coef + (k >> 1) * chead) + (k & 1) * 64;
+    }
+    uint32_t v = 0;
+    if (lane < 25 + 2 * NCOEF) v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a));
+    return v;
+}
+__device__ __forceinline__ void prefetch_done(uint32_t v) { asm volatile("" ::"v"(v)); }
+
+// One 64-token block against coefficient row `qw` (head stride `chead` pairs) -> acc[h] for lane = token.
 template <int G>
 __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off,
                                            const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
@@ -164,20 +310,28 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
                                            uint32_t chead, int lane, float (&acc)[G])
 {
     unsigned char* lds = smem + lds_off;
-    uint32_t i0 = idx_t[0], i1 = idx_t[kChunkTiles];
-    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (i1 - i0), lane);
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);   // low half of a flat LDS pointer = LDS offset
+    const uint32_t pf = prefetch_meta<0>(bmp_t, idx_t, qw, chead, lane);
+    const uint32_t bnd = bnd_load(idx_t, lane);
+    uint32_t i0 = bnd_get(bnd, 0);
+    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (bnd_get(bnd, 1) - i0), lane);
     stage_commit(lds, st, lane);
+    prefetch_done(pf);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        uint32_t n0 = 0, n1 = 0;
+        uint32_t n0 = 0;
         if (c < 3) {
-            n0 = idx_t[(c + 1) * kChunkTiles];
-            n1 = idx_t[(c + 2) * kChunkTiles];
-            st = stage_issue(nz_h + 4ull * n0, 4u * (n1 - n0), lane);
+            n0 = bnd_get(bnd, c + 1);
+            st = stage_issue(nz_h + 4ull * n0, 4u * (bnd_get(bnd, c + 2) - n0), lane);
         }
         __builtin_amdgcn_wave_barrier();
-        chunk32<G>(smem, lds_off - 4u * i0, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles,
-                   qw + c * (kChunkTiles / 2), chead, acc);
+        {
+            const h16x2* cp[G];
+#pragma unroll
+            for (int h = 0; h < G; h++) cp[h] = qw + h * chead + c * (kChunkTiles / 2);
+            const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
+            chunk32<G>(adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cp, acc);
+        }
         __builtin_amdgcn_wave_barrier();
         if (c < 3) {
             stage_commit(lds, st, lane);
@@ -238,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
 
 // ------------------------------------------------------------------------------------------------ value
 // Accumulate token blocks tb_first, tb_first+4, ... < tb_end of one kv-head: lane = channel,
-// acc0 = channels 0..63, acc1 = channels 64..127, coefficient row `pw` (head stride `chead` words).
+// acc0 = channels 0..63, acc1 = channels 64..127, coefficient row `pw` (head stride `chead` pairs).
 template <int G>
 __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_off,
                                               const uint64_t* __restrict__ bmp_h, const uint32_t* __restrict__ idx_h,
@@ -248,40 +402,49 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
 {
     if (tb_first >= tb_end) return;
     unsigned char* lds = smem + lds_off;
-    uint32_t i0 = idx_h[(int64_t)tb_first * kTilesPerTb];
-    Stage st;
-    {
-        const uint32_t i1 = idx_h[(int64_t)tb_first * kTilesPerTb + kChunkTiles];
-        st = stage_issue(nz_h + 4ull * i0, 4u * (i1 - i0), lane);
-        stage_commit(lds, st, lane);
-    }
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    uint32_t pf = prefetch_meta<G>(bmp_h + (int64_t)tb_first * kTilesPerTb, idx_h + (int64_t)tb_first * kTilesPerTb,
+                                   pw + (uint32_t)tb_first * 32u, chead, lane);
+    uint32_t bnd = bnd_load(idx_h + (int64_t)tb_first * kTilesPerTb, lane);
+    uint32_t i0 = bnd_get(bnd, 0);
+    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (bnd_get(bnd, 1) - i0), lane);
+    stage_commit(lds, st, lane);
     for (int tb = tb_first; tb < tb_end; tb += kWaves) {
         const uint64_t* bmp_t = bmp_h + (int64_t)tb * kTilesPerTb;
         const uint32_t* idx_t = idx_h + (int64_t)tb * kTilesPerTb;
         const bool more = tb + kWaves < tb_end;
+        prefetch_done(pf);
+        // metadata lines and chunk bounds of the wave's next token block, in flight while this one is processed
+        const int tbn = more ? tb + kWaves : tb;
+        pf = prefetch_meta<G>(bmp_h + (int64_t)tbn * kTilesPerTb, idx_h + (int64_t)tbn * kTilesPerTb,
+                              pw + (uint32_t)tbn * 32u, chead, lane);
+        const uint32_t bnd_next = bnd_load(more ? idx_t + kWaves * kTilesPerTb : idx_t, lane);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            uint32_t n0 = 0, n1 = 0;
+            uint32_t n0 = 0;
             const bool has_next = (c < 3) || more;
             if (has_next) {
-                const uint32_t* idx_n = (c < 3) ? idx_t + (c + 1) * kChunkTiles : idx_t + kWaves * kTilesPerTb;
-                n0 = idx_n[0];
-                n1 = idx_n[kChunkTiles];
+                n0 = (c < 3) ? bnd_get(bnd, c + 1) : bnd_get(bnd_next, 0);
+                const uint32_t n1 = (c < 3) ? bnd_get(bnd, c + 2) : bnd_get(bnd_next, 1);
                 st = stage_issue(nz_h + 4ull * n0, 4u * (n1 - n0), lane);
             }
             __builtin_amdgcn_wave_barrier();
             // chunk c: channel half = c >> 1, tokens (c & 1) * 32 .. +31 of the block
-            const h16x2* cw = pw + ((uint32_t)tb * 64u + (c & 1) * 32u) / 2u;
-            const uint32_t adj = lds_off - 4u * i0;
-            if (c < 2) chunk32<G>(smem, adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cw, chead, acc0);
-            else       chunk32<G>(smem, adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cw, chead, acc1);
+            const h16x2* cp[G];
+#pragma unroll
+            for (int h = 0; h < G; h++) cp[h] = pw + h * chead + ((uint32_t)tb * 64u + (c & 1) * 32u) / 2u;
+            const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
+            if (c < 2) chunk32<G>(adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cp, acc0);
+            else       chunk32<G>(adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cp, acc1);
             __builtin_amdgcn_wave_barrier();
             if (has_next) {
                 stage_commit(lds, st, lane);
                 i0 = n0;
             }
         }
+        bnd = bnd_next;
     }
+    prefetch_done(pf);
 }
 
 // grid: x = Split_K token chunks, y = kv-heads * (groups / G)
