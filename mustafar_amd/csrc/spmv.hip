@@ -297,7 +297,7 @@ __device__ __forceinline__ uint32_t prefetch_meta(const uint64_t* __restrict__ b
         a = reinterpret_cast<const unsigned char*>(coef + (k >> 1) * chead) + (k & 1) * 64;
     }
     uint32_t v = 0;
-    if (lane < 25 + 2 * NCOEF) v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a));
+    if (lane < 25 + 2 * NCOEF) v = *reinterpret_cast<const uint32_t*>(a);
     return v;
 }
 __device__ __forceinline__ void prefetch_done(uint32_t v) { asm volatile("" ::"v"(v)); }
@@ -515,22 +515,38 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
 
 // out[bh, n, c] = fp16( sum_s ws[s, bh, n, c] ), pad rows only from the slabs whose row mask has them.
 // (the role of the reference's SplitK_Reduction, Reduction_Kernel.cuh:26-48, with fp32 partials)
+// One workgroup per output row (bh, n): thread = (channel, slab parity); independent loads, LDS fold of the halves.
 __global__ __launch_bounds__(256) void value_combine_kernel(const float* __restrict__ ws,
                                                             const uint32_t* __restrict__ flags, h16* __restrict__ out,
                                                             int BH, int N, int S, int groups, int G)
 {
-    const int64_t total = (int64_t)BH * N * kD;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int n  = (int)((i / kD) % N);
-    const int bh = (int)(i / ((int64_t)kD * N));
+    __shared__ float part[kD];
+    const int row = blockIdx.x;            // bh * N + n
+    const int n = row % N, bh = row / N;
+    const int c = threadIdx.x & (kD - 1), par = threadIdx.x >> 7;
     const int hb_per_kv = groups / G;
     const int y  = (bh / groups) * hb_per_kv + (bh % groups) / G;   // blockIdx.y of the producer
     const int gy = (BH / groups) * hb_per_kv;
-    float s = 0.f;
-    for (int k = 0; k < S; k++)
-        if (n == 0 || ((flags[k * gy + y] >> n) & 1u)) s += ws[(int64_t)k * total + i];
-    out[i] = (h16)s;
+    const int64_t total = (int64_t)BH * N * kD;
+    const float* src = ws + (int64_t)row * kD + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = par;
+    if (n == 0) {
+        for (; k + 6 < S; k += 8) {
+            s0 += src[(int64_t)k * total];
+            s1 += src[(int64_t)(k + 2) * total];
+            s2 += src[(int64_t)(k + 4) * total];
+            s3 += src[(int64_t)(k + 6) * total];
+        }
+        for (; k < S; k += 2) s0 += src[(int64_t)k * total];
+    } else {
+        for (; k < S; k += 2)
+            if ((flags[k * gy + y] >> n) & 1u) s0 += src[(int64_t)k * total];
+    }
+    const float s = (s0 + s1) + (s2 + s3);
+    if (par) part[c] = s;
+    __syncthreads();
+    if (!par) out[(int64_t)row * kD + c] = (h16)(s + part[c]);
 }
 
 inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : 1; }
@@ -636,8 +652,7 @@ int Value_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const
     }
     int err = (int)hipGetLastError();
     if (err || direct) return err;
-    const int64_t total = (int64_t)Batch_Size * N * kD;
-    value_combine_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(ws, flags, o, Batch_Size, N, S, groups, G);
+    value_combine_kernel<<<(unsigned)(Batch_Size * N), 256, 0, st>>>(ws, flags, o, Batch_Size, N, S, groups, G);
     return (int)hipGetLastError();
 }
 
