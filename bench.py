@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-reference-api", action="store_true", help="skip the second timing with the reference call sequence")
+    ap.add_argument("--no-reference-api", action="store_true", help="skip the extra timings through the two reference entry points")
+    ap.add_argument("--no-graph", action="store_true", help="fused api without hipGraph capture of the step")
+    ap.add_argument("--api", default="fused", choices=["fused", "native", "reference"], help="call sequence timed for `value`")
     return ap.parse_args()
 
 
@@ -151,40 +153,120 @@ def main():
         for l in range(a.layers):
             _, state[l] = attn.decode(qs[l], ks[l], vs[l], state[l])
 
-    def timed(api, steps, warmup):
-        cfg.api = api
-        state = list(pasts)                    # decode() never mutates a past in place: the base caches stay intact
-        for _ in range(warmup):
-            one_step(state)
-        timer.reset()
-        timer.enabled = True
+    import ctypes
+    from mustafar_amd import _lib
+    lib = _lib.load()
+
+    def bracket(run_steps):
+        """barrier + synchronize on both sides, max over ranks (the contract's timed region)."""
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            one_step(state)
+        run_steps()
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
-        timer.enabled = False
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
-    dt = timed("native", a.steps, a.warmup)
-    key_us, n_key = timer.avg_us("key")
-    val_us, n_val = timer.avg_us("value")
-    ref = None
+    def timed(api, steps, warmup):
+        """Eager call sequence `api`; per-kernel HIP events are recorded live inside the timed region."""
+        cfg.api = api
+        # decode() never mutates a reference-layout past in place; the fused api appends to its windows, so it
+        # gets private copies of them (to_fused copies the window tensors into fresh buffers)
+        state = [attn.to_fused(p) for p in pasts] if api == "fused" else list(pasts)
+        for _ in range(warmup):
+            one_step(state)
+        timer.reset()
+        timer.enabled = api != "fused"
+        if api == "fused":
+            _lib.check(lib.mustafar_profile_begin(steps * a.layers), "mustafar_profile_begin")
+        dt = bracket(lambda: [one_step(state) for _ in range(steps)])
+        timer.enabled = False
+        if api == "fused":
+            ku, vu, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+            _lib.check(lib.mustafar_profile_end(ctypes.byref(ku), ctypes.byref(vu), ctypes.byref(n)), "mustafar_profile_end")
+            kern = (ku.value, vu.value, n.value)
+        else:
+            kern = (timer.avg_us("key")[0], timer.avg_us("value")[0], len(timer.events["key"]))
+        return dt, kern
+
+    def timed_graph(steps, warmup):
+        """The fused call sequence of a whole step (all layers) captured ONCE into a hipGraph and replayed per step;
+        a device-side counter grows the windows between replays.  A step that fires the 256-token compression
+        trigger (model :324) runs eagerly and the graph is re-captured after it."""
+        cfg.api = "fused"
+        state = [attn.to_fused(p) for p in pasts]
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        warm = [(state[0][0], state[0][1].clone(), state[0][2], state[0][3].clone(), state[0][4], state[0][5])]
+        attn.decode_fused(qs[0], ks[0], vs[0], warm[0])          # allocates the scratch buffers outside the capture
+        torch.cuda.synchronize(dev)
+        box = {"g": None, "since": 0}
+
+        def capture():
+            counter.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for l in range(a.layers):
+                    attn.decode_fused(qs[l], ks[l], vs[l], state[l], step_counter=counter)
+                _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream(dev).cuda_stream, counter.data_ptr(), 1), "counter_add")
+            box["g"], box["since"] = g, 0
+
+        def until_trigger():
+            p = state[0]
+            return 256 - ((p[5] + box["since"] - R - p[4]) % 256)
+
+        def step():
+            if until_trigger() == 1:
+                for l in range(a.layers):
+                    state[l] = attn.advance(state[l], box["since"])
+                one_step(state)                  # eager: prune + compress + append inside decode_fused
+                capture()
+            else:
+                box["g"].replay()
+                box["since"] += 1
+
+        capture()
+        for _ in range(warmup):
+            step()
+        dt = bracket(lambda: [step() for _ in range(steps)])
+        for l in range(a.layers):
+            state[l] = attn.advance(state[l], box["since"])
+        # per-kernel HIP events: same steps again, eagerly, right after the timed replays (events cannot sit between
+        # the kernels of a replayed graph)
+        _lib.check(lib.mustafar_profile_begin(steps * a.layers), "mustafar_profile_begin")
+        for _ in range(steps):
+            one_step(state)
+        ku, vu, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(lib.mustafar_profile_end(ctypes.byref(ku), ctypes.byref(vu), ctypes.byref(n)), "mustafar_profile_end")
+        return dt, (ku.value, vu.value, n.value)
+
+    if a.api == "fused" and not a.no_graph:
+        dt, (key_us, val_us, n_key) = timed_graph(a.steps, a.warmup)
+    else:
+        dt, (key_us, val_us, n_key) = timed(a.api, a.steps, a.warmup)
+    n_val = n_key
+    API_NOTE = {
+        "fused": "mustafar_decode_attention (C ABI extension): key SpMV -> window scores + softmax -> value SpMV -> combine + window p.V, one call per layer"
+                 + ("" if a.no_graph else "; the whole step captured once in a hipGraph and replayed"),
+        "native": "the two reference entry points with un-padded (N=1) operands and a flat stream; PyTorch glue between them",
+        "reference": "exact reference call sequence: q/p zero-padded to 8 rows, torch.cat of per-head streams per call, 8-row outputs, PyTorch glue",
+    }
+    others = {}
     if not a.no_reference_api:
-        dt_ref = timed("reference", max(2, a.steps // 2), 1)
-        ref = {"value": world * batch * max(2, a.steps // 2) / dt_ref, "unit": "tokens/s",
-               "ms_per_step": dt_ref / max(2, a.steps // 2) * 1e3,
-               "key_call_us": round(timer.avg_us("key")[0], 2), "value_call_us": round(timer.avg_us("value")[0], 2),
-               "note": "exact reference call sequence: q/p zero-padded to 8 rows, torch.cat of per-head streams per call, 8-row outputs"}
+        for api in ("fused", "native", "reference"):
+            if api == a.api and (api != "fused" or a.no_graph):
+                continue
+            st_ = max(2, a.steps // 2)
+            dt_o, (ku, vu, _) = timed(api, st_, 1)
+            others[api] = {"value": round(world * batch * st_ / dt_o, 2), "unit": "tokens/s", "ms_per_step": round(dt_o / st_ * 1e3, 4),
+                           "key_call_us": round(ku, 2), "value_call_us": round(vu, 2),
+                           "note": (API_NOTE[api] if api != "fused" else API_NOTE[api].split(";")[0] + "; eager (no graph)")}
     alloc_peak = torch.cuda.max_memory_allocated(dev)
 
     if rank != 0:
@@ -230,10 +312,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": label, "id": a.config, "layers": a.layers, "q_heads": Hq, "kv_heads": Hkv, "head_dim": D,
                    "sparsity": s, "seq_len": L, "compressed_tokens": T, "batch_per_gpu": batch, "residual_length": R,
-                   "api": "mustafar_package entry points, un-padded (N=1) operands", "parallelism": f"replicas x{world}"},
+                   "api": a.api, "api_note": API_NOTE[a.api], "parallelism": f"replicas x{world}"},
         "peak_kv_bytes": int(kv_bytes), "dense_kv_bytes": int(dense_bytes), "kv_compression_ratio": round(dense_bytes / kv_bytes, 3),
         "allocator_peak_bytes": int(alloc_peak),
-        "roofline": roofline, "cpu_baseline": cpu, "reference_call_sequence": ref,
+        "roofline": roofline, "cpu_baseline": cpu, "other_call_sequences": others,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:

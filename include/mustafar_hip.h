@@ -90,6 +90,39 @@ int mustafar_compress_pack_key(void* stream, const void* x, int Bp, int t, int D
 int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int D, const int64_t* bmp,
                                  const int32_t* accum, const int64_t* head_off, void* nz_flat);
 
+/*
+ * Fused decode attention of one layer (extension).  Replaces the PyTorch glue of the reference hook
+ * between the two SpMVs (models/llama_mustafar_kernel.py:270-317): window append, q.K_window^T, concat, / sqrt(d),
+ * fp32 softmax, p.V_window, sum.  Four launches on `stream`: key SpMV -> window scores + softmax -> value SpMV ->
+ * combine + window p.V.  All operands fp16 unless noted; B' = Batch_Size / num_key_value_groups.
+ *   q            [Batch_Size, 128]
+ *   k_window     [B', window_capacity, 128]  rows [0, window_len) valid after the call; k_new [B', 128] (or NULL if the
+ *   v_window     same                        newest row is already stored) is appended at row window_len - 1
+ *   scores       [Batch_Size, ld_scores] scratch (scores, then probabilities); ld_scores >= T + window_len, % 8 == 0
+ *   out          [Batch_Size, 128]
+ *   workspace    mustafar_decode_workspace_bytes() bytes (fp32 partial slabs); Split_K as for Value_SplitK_API
+ *   T            compressed tokens (multiple of 64, 0 allowed: window only); sqrt_d = sqrt(head_dim)
+ *   window_len_extra  NULL, or a device int added to window_len inside the kernels (clamped to the capacity):
+ *                lets a captured hipGraph of a whole decode step be replayed while the windows keep growing;
+ *                advance it once per step with mustafar_counter_add().  ld_scores must then cover the capacity.
+ */
+int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k_nz, const uint32_t* k_idx,
+                              const uint32_t* k_nz_offset, const uint64_t* v_bmp, const void* v_nz, const uint32_t* v_idx,
+                              const uint32_t* v_nz_offset, const void* q, void* k_window, void* v_window, const void* k_new,
+                              const void* v_new, int window_len, int window_capacity, void* scores, int ld_scores, void* out,
+                              void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
+                              const int32_t* window_len_extra);
+int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value_groups, int Split_K);
+int mustafar_counter_add(void* stream, int32_t* counter, int delta);
+
+/*
+ * Live kernel timing inside mustafar_decode_attention (bench.py roofline leg): HIP events recorded on the launch
+ * stream around the key and the value SpMV kernels of up to `max_records` calls.  mustafar_profile_end() waits for
+ * the recorded events, returns the average durations in microseconds and releases the events.
+ */
+int mustafar_profile_begin(int max_records);
+int mustafar_profile_end(double* key_us_avg, double* value_us_avg, int* records);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,11 @@ SIGNATURES = {
     "Value_SplitK_API": (_i32, [_vp] * 8 + [_i32] * 3 + [_vp] + [_i32] * 3),
     "mustafar_value_pick_split_k": (_i32, [_i32] * 5),
     "mustafar_value_workspace_bytes": (_i64, [_i32] * 6),
+    "mustafar_decode_attention": (_i32, [_vp] * 14 + [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_float, _vp]),
+    "mustafar_counter_add": (_i32, [_vp, _vp, _i32]),
+    "mustafar_decode_workspace_bytes": (_i64, [_i32] * 4),
+    "mustafar_profile_begin": (_i32, [_i32]),
+    "mustafar_profile_end": (_i32, [_vp, _vp, _vp]),
     "mustafar_prune_magnitude": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32]),
     "mustafar_compress_bitmap_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mustafar_compress_bitmap_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),

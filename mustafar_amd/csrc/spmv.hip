@@ -344,7 +344,8 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
 template <int G>
 __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
-    const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int N, int groups)
+    const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int N, int groups,
+    int ldc)   // ldc: row stride of `out` in halfs (T for the reference layout)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16];
     const int lane = threadIdx.x & 63;
@@ -377,14 +378,14 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
                 key_tokblk<G>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc);
 #pragma unroll
                 for (int h = 0; h < G; h++)
-                    out[((int64_t)(bh0 + h) * N + n) * T + (int64_t)tb * 64 + lane] = (h16)acc[h];
+                    out[((int64_t)(bh0 + h) * N + n) * ldc + (int64_t)tb * 64 + lane] = (h16)acc[h];
             }
         } else {   // exact zeros, 16 bytes per lane
             const int per_row = ntok / 8;
             const uint4 z = {0u, 0u, 0u, 0u};
             for (int u = threadIdx.x; u < G * per_row; u += kThreads) {
                 const int h = u / per_row, k = u % per_row;
-                *reinterpret_cast<uint4*>(out + ((int64_t)(bh0 + h) * N + n) * T + tok0 + k * 8) = z;
+                *reinterpret_cast<uint4*>(out + ((int64_t)(bh0 + h) * N + n) * ldc + tok0 + k * 8) = z;
             }
         }
     }
@@ -454,8 +455,8 @@ template <int G>
 __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
-    uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct)
-{
+    uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb)
+{   // ldb: row stride of `p` in halfs (T for the reference layout; must be even)
     __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16];
     static_assert(kWaves * kStageBytes >= kWaves * 2 * 4 * 64 * 4, "reduce buffer must fit in the stage area");
     const int lane = threadIdx.x & 63;
@@ -473,11 +474,11 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
     const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
     float* red = reinterpret_cast<float*>(smem);   // [kWaves][2*G][64], overlays the stage windows
     float* ws_slab = ws + (int64_t)blockIdx.x * BH * N * kD;
-    const uint32_t chead = (uint32_t)N * ((uint32_t)T / 2u);
+    const uint32_t chead = (uint32_t)N * ((uint32_t)ldb / 2u);
 
     uint32_t rows = 1u;
     if (N > 1) {
-        rows |= pad_row_mask<G>(p, T, bh0, N, tb0 * 64, (tb_end - tb0) * 64,
+        rows |= pad_row_mask<G>(p, ldb, bh0, N, tb0 * 64, (tb_end - tb0) * 64,
                                 reinterpret_cast<uint32_t*>(smem + kWaves * kStageBytes));
         if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + blockIdx.y] = rows;
     }
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
 #pragma unroll
         for (int h = 0; h < G; h++) acc0[h] = acc1[h] = 0.f;
         if (live) {
-            const h16x2* pw = reinterpret_cast<const h16x2*>(p + ((int64_t)bh0 * N + n) * T);
+            const h16x2* pw = reinterpret_cast<const h16x2*>(p + ((int64_t)bh0 * N + n) * ldb);
             value_tokblks<G>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb0 + wave, tb_end, lane, acc0,
                              acc1);
         }
@@ -549,7 +550,198 @@ __global__ __launch_bounds__(256) void value_combine_kernel(const float* __restr
     if (!par) out[(int64_t)row * kD + c] = (h16)(s + part[c]);
 }
 
+// ------------------------------------------------------------------------------------------------ fused decode glue
+// Replaces the PyTorch glue between the two SpMVs in the reference hook (llama_mustafar_kernel.py:270-317):
+// window append (:270), q.K_window^T (:278), concat (:279), / sqrt(d) (:284), fp32 softmax -> fp16 (:304),
+// p.V_window (:316) and the final sum (:317).  Both kernels run one workgroup per (batch, q-head) row and are
+// latency-bound, so they are written for memory-level parallelism: 16-byte loads, everything a thread needs in
+// flight at once, the score row kept in registers between the softmax sweeps.
+constexpr int kGlueThreads = 512;
+constexpr int kGlueWaves   = kGlueThreads / 64;
+constexpr int kMaxRowVecs  = 8;     // 16-byte vectors of the score row a thread keeps in registers (T <= 32768)
+constexpr int kMaxWindow   = 1024;  // window tokens whose scores are staged in LDS
+
+template <int NW>
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float u = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, u) : v + u;
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[wave] = v;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) r = is_max ? fmaxf(r, sh[w]) : r + sh[w];
+    return r;
+}
+
+// x = fp16(score / sqrt(d)) like the reference (an fp16 tensor divided by a Python float, :284), then fp32 (:304).
+// The quotient is formed as a product with 1/sqrt(d): at most 1 fp32 ulp away before the fp16 rounding.
+__device__ __forceinline__ float scaled(h16 a, float inv_sqrt_d) { return (float)(h16)((float)a * inv_sqrt_d); }
+
+union Vec8 {
+    uint4 u;
+    h16 h[8];
+};
+
+__global__ __launch_bounds__(kGlueThreads) void window_softmax_kernel(
+    const h16* __restrict__ q, h16* __restrict__ k_win, const h16* __restrict__ k_new, h16* __restrict__ scores,
+    int T, int ld, int w_len, int w_cap, int groups, float inv_sqrt_d, const int* __restrict__ w_extra)
+{
+    __shared__ float sh[kGlueWaves];
+    __shared__ h16 wsc[kMaxWindow];
+    if (w_extra) w_len = min(w_len + *w_extra, w_cap);   // device-side step counter (graph replay): tokens appended so far
+    const int bh = blockIdx.x, kvh = bh / groups;
+    const int tid = threadIdx.x;
+    h16* row = scores + (int64_t)bh * ld;
+
+    // (1) score row of the compressed part -> registers (issued first: the longest latency)
+    const int nvec = T / 8;
+    Vec8 x[kMaxRowVecs];
+#pragma unroll
+    for (int i = 0; i < kMaxRowVecs; i++) {
+        const int v = tid + i * kGlueThreads;
+        x[i].u = (v < nvec) ? reinterpret_cast<const uint4*>(row)[v] : make_uint4(0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u);  // -inf
+    }
+
+    // (2) window scores: 16 lanes per token (8 channels each), 32 tokens per sweep; fp32 accumulate, fp16 result (:278)
+    const int sub = tid & 15, grp = tid >> 4;
+    Vec8 qv;
+    qv.u = reinterpret_cast<const uint4*>(q + (int64_t)bh * kD)[sub];
+    const h16* knew = k_new ? k_new + (int64_t)kvh * kD : nullptr;
+    if (knew && bh % groups == 0 && tid < 16)   // the group's first head stores the new key row (:270)
+        reinterpret_cast<uint4*>(k_win + ((int64_t)kvh * w_cap + (w_len - 1)) * kD)[tid] = reinterpret_cast<const uint4*>(knew)[tid];
+    for (int w0 = 0; w0 < w_len; w0 += kGlueThreads / 16) {
+        const int w = w0 + grp;
+        float sdot = 0.f;
+        if (w < w_len) {
+            const h16* kr = (knew && w == w_len - 1) ? knew : k_win + ((int64_t)kvh * w_cap + w) * kD;
+            Vec8 kv;
+            kv.u = reinterpret_cast<const uint4*>(kr)[sub];
+#pragma unroll
+            for (int j = 0; j < 8; j++) sdot = __builtin_fmaf((float)qv.h[j], (float)kv.h[j], sdot);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o);
+        if (sub == 0 && w < w_len && w < kMaxWindow) wsc[w] = (h16)sdot;
+    }
+    __syncthreads();
+
+    // (3) fp32 softmax over x_i = fp16(score_i / sqrt(d))  (:284, :304)
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kMaxRowVecs; i++)
+        if (i * kGlueThreads < nvec) {   // workgroup-uniform: skip register slots beyond the row
+#pragma unroll
+            for (int j = 0; j < 8; j++) m = fmaxf(m, scaled(x[i].h[j], inv_sqrt_d));
+        }
+    for (int w = tid; w < w_len; w += kGlueThreads) m = fmaxf(m, scaled(wsc[w], inv_sqrt_d));
+    m = block_reduce<kGlueWaves>(m, true, sh);
+    float l = 0.f;
+    float e[kMaxRowVecs][8];
+#pragma unroll
+    for (int i = 0; i < kMaxRowVecs; i++)
+        if (i * kGlueThreads < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                e[i][j] = __expf(scaled(x[i].h[j], inv_sqrt_d) - m);   // exp(-inf) = 0 for the padding lanes
+                l += e[i][j];
+            }
+        }
+    for (int w = tid; w < w_len; w += kGlueThreads) l += __expf(scaled(wsc[w], inv_sqrt_d) - m);
+    l = block_reduce<kGlueWaves>(l, false, sh);
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int i = 0; i < kMaxRowVecs; i++) {
+        const int v = tid + i * kGlueThreads;
+        if (v < nvec) {
+            Vec8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o.h[j] = (h16)(e[i][j] * inv);
+            reinterpret_cast<uint4*>(row)[v] = o.u;
+        }
+    }
+    for (int w = tid; w < w_len; w += kGlueThreads) row[T + w] = (h16)(__expf(scaled(wsc[w], inv_sqrt_d) - m) * inv);
+}
+
+__global__ void counter_add_kernel(int* ctr, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += delta; }
+
+// out[bh, c] = fp16( sum_s ws[s, bh, c] + sum_w p[bh, T + w] * V_window[kvh, w, c] )   (:315-317), and window append (:309).
+// 256 threads: 16 lanes per window row (8 channels each) x 16 rows per sweep; slab sums on (channel, parity).
+__global__ __launch_bounds__(256) void value_finish_kernel(
+    const float* __restrict__ ws, int S, const h16* __restrict__ probs, int ld, int T, h16* __restrict__ v_win,
+    const h16* __restrict__ v_new, int w_len, int w_cap, h16* __restrict__ out, int BH, int groups,
+    const int* __restrict__ w_extra)
+{
+    __shared__ float red[16][kD + 4];
+    __shared__ float part[kD];
+    if (w_extra) w_len = min(w_len + *w_extra, w_cap);
+    const int bh = blockIdx.x, kvh = bh / groups;
+    const int tid = threadIdx.x;
+    // window p.V
+    const int sub = tid & 15, grp = tid >> 4;
+    const h16* vnew = v_new ? v_new + (int64_t)kvh * kD : nullptr;
+    if (vnew && bh % groups == 0 && tid < 16)
+        reinterpret_cast<uint4*>(v_win + ((int64_t)kvh * w_cap + (w_len - 1)) * kD)[tid] = reinterpret_cast<const uint4*>(vnew)[tid];
+    const h16* pr = probs + (int64_t)bh * ld + T;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+#pragma unroll 4
+    for (int w = grp; w < w_len; w += 16) {
+        const h16* vr = (vnew && w == w_len - 1) ? vnew : v_win + ((int64_t)kvh * w_cap + w) * kD;
+        Vec8 vv;
+        vv.u = reinterpret_cast<const uint4*>(vr)[sub];
+        const float pw = (float)pr[w];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(pw, (float)vv.h[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) red[grp][sub * 8 + j] = acc[j];
+    // slab sums: thread = (channel, slab parity), independent loads
+    const int c = tid & (kD - 1), par = tid >> 7;
+    const int64_t total = (int64_t)BH * kD;
+    const float* src = ws + (int64_t)bh * kD + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = par;
+    for (; k + 6 < S; k += 8) {
+        s0 += src[(int64_t)k * total];
+        s1 += src[(int64_t)(k + 2) * total];
+        s2 += src[(int64_t)(k + 4) * total];
+        s3 += src[(int64_t)(k + 6) * total];
+    }
+    for (; k < S; k += 2) s0 += src[(int64_t)k * total];
+    float s = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (par) {
+        part[c] = s;
+    } else {
+#pragma unroll
+        for (int g = 0; g < 16; g++) s += red[g][c];
+    }
+    __syncthreads();
+    if (!par) out[(int64_t)bh * kD + c] = (h16)(s + part[c]);
+}
+
 inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : 1; }
+
+// Optional live timing of the two SpMV kernels inside mustafar_decode_attention (bench.py's roofline leg): HIP
+// events recorded on the launch stream right around each kernel.  Off by default; not thread-safe by design
+// (the hook is single-threaded, mustafar_wrapper.cu holds the GIL throughout as well).
+struct Profile {
+    bool on = false;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;   // 4 per record: key begin/end, value begin/end
+} g_prof;
+
+inline void prof_mark(hipStream_t st, int which)
+{
+    if (g_prof.on && g_prof.n < g_prof.cap) (void)hipEventRecord(g_prof.ev[4 * g_prof.n + which], st);
+}
 
 }  // namespace
 
@@ -573,9 +765,9 @@ int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const v
     auto q  = static_cast<const h16*>(B);
     auto o  = static_cast<h16*>(C);
     switch (G) {
-        case 4: key_spmv_kernel<4><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups); break;
-        case 2: key_spmv_kernel<2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups); break;
-        default: key_spmv_kernel<1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups); break;
+        case 4: key_spmv_kernel<4><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
+        case 2: key_spmv_kernel<2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
+        default: key_spmv_kernel<1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
     }
     return (int)hipGetLastError();
 }
@@ -639,20 +831,128 @@ int Value_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const
     switch (G) {
         case 4:
             value_spmv_kernel<4><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
-                                                            Batch_Size, tb_per_wg, direct);
+                                                            Batch_Size, tb_per_wg, direct, T);
             break;
         case 2:
             value_spmv_kernel<2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
-                                                            Batch_Size, tb_per_wg, direct);
+                                                            Batch_Size, tb_per_wg, direct, T);
             break;
         default:
             value_spmv_kernel<1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
-                                                            Batch_Size, tb_per_wg, direct);
+                                                            Batch_Size, tb_per_wg, direct, T);
             break;
     }
     int err = (int)hipGetLastError();
     if (err || direct) return err;
     value_combine_kernel<<<(unsigned)(Batch_Size * N), 256, 0, st>>>(ws, flags, o, Batch_Size, N, S, groups, G);
+    return (int)hipGetLastError();
+}
+
+
+int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value_groups, int Split_K)
+{
+    (void)T; (void)num_key_value_groups;
+    return (int64_t)(Split_K < 1 ? 1 : Split_K) * Batch_Size * kD * (int64_t)sizeof(float);
+}
+
+int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k_nz, const uint32_t* k_idx,
+                              const uint32_t* k_nz_offset, const uint64_t* v_bmp, const void* v_nz, const uint32_t* v_idx,
+                              const uint32_t* v_nz_offset, const void* q, void* k_window, void* v_window, const void* k_new,
+                              const void* v_new, int window_len, int window_capacity, void* scores, int ld_scores, void* out,
+                              void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
+                              const int32_t* window_len_extra)
+{
+    const int groups = num_key_value_groups;
+    if (T < 0 || (T & 63) || groups < 1 || Batch_Size < 1 || Batch_Size % groups || window_len < 1 ||
+        window_len > window_capacity || window_capacity > kMaxWindow || T > kMaxRowVecs * kGlueThreads * 8 ||
+        ld_scores < T + (window_len_extra ? window_capacity : window_len) || (ld_scores & 7) || Split_K < 1 || !(sqrt_d > 0.f))
+        return MUSTAFAR_EINVAL;
+    if (!q || !k_window || !v_window || !scores || !out || !workspace) return MUSTAFAR_EINVAL;
+    if (T > 0 && (!k_bmp || !k_nz || !k_idx || !k_nz_offset || !v_bmp || !v_nz || !v_idx || !v_nz_offset)) return MUSTAFAR_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto qh = static_cast<const h16*>(q);
+    auto sc = static_cast<h16*>(scores);
+    const int G = pick_g(groups);
+    const int gy = (Batch_Size / groups) * (groups / G);
+    int S = 0;
+    const bool prof = g_prof.on && g_prof.n < g_prof.cap && T > 0;
+    if (T > 0) {
+        const dim3 gk((T / 64 + kWaves - 1) / kWaves, gy);
+        if (prof) prof_mark(st, 0);
+        auto nz = static_cast<const unsigned char*>(k_nz);
+        switch (G) {
+            case 4: key_spmv_kernel<4><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
+            case 2: key_spmv_kernel<2><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
+            default: key_spmv_kernel<1><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
+        }
+        if (prof) prof_mark(st, 1);
+    }
+    window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, static_cast<h16*>(k_window), static_cast<const h16*>(k_new), sc,
+                                                               T, ld_scores, window_len, window_capacity, groups,
+                                                               (float)(1.0 / (double)sqrt_d), window_len_extra);
+    float* ws = static_cast<float*>(workspace);
+    if (T > 0) {
+        const int ntb = T / 64;
+        const int tb_per_wg = (ntb + Split_K - 1) / Split_K;
+        S = (ntb + tb_per_wg - 1) / tb_per_wg;
+        const dim3 gv(S, gy);
+        auto nz = static_cast<const unsigned char*>(v_nz);
+        h16* no_out = nullptr;
+        uint32_t* no_flags = nullptr;
+        if (prof) prof_mark(st, 2);
+        switch (G) {
+            case 4: value_spmv_kernel<4><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
+            case 2: value_spmv_kernel<2><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
+            default: value_spmv_kernel<1><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
+        }
+        if (prof) { prof_mark(st, 3); g_prof.n++; }
+    }
+    value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S, sc, ld_scores, T, static_cast<h16*>(v_window), static_cast<const h16*>(v_new),
+                                                    window_len, window_capacity, static_cast<h16*>(out), Batch_Size, groups,
+                                                    window_len_extra);
+    return (int)hipGetLastError();
+}
+
+
+int mustafar_profile_begin(int max_records)
+{
+    if (g_prof.ev || max_records < 1) return MUSTAFAR_EINVAL;
+    g_prof.ev = new hipEvent_t[4 * (size_t)max_records];
+    for (int i = 0; i < 4 * max_records; i++)
+        if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return (int)hipGetLastError();
+    g_prof.cap = max_records;
+    g_prof.n = 0;
+    g_prof.on = true;
+    return 0;
+}
+
+int mustafar_profile_end(double* key_us_avg, double* value_us_avg, int* records)
+{
+    if (!g_prof.ev) return MUSTAFAR_EINVAL;
+    g_prof.on = false;
+    double k = 0, v = 0;
+    for (int i = 0; i < g_prof.n; i++) {
+        float ms = 0;
+        (void)hipEventSynchronize(g_prof.ev[4 * i + 3]);
+        (void)hipEventElapsedTime(&ms, g_prof.ev[4 * i], g_prof.ev[4 * i + 1]);
+        k += ms * 1e3;
+        (void)hipEventElapsedTime(&ms, g_prof.ev[4 * i + 2], g_prof.ev[4 * i + 3]);
+        v += ms * 1e3;
+    }
+    if (records) *records = g_prof.n;
+    if (key_us_avg) *key_us_avg = g_prof.n ? k / g_prof.n : 0;
+    if (value_us_avg) *value_us_avg = g_prof.n ? v / g_prof.n : 0;
+    for (int i = 0; i < 4 * g_prof.cap; i++) (void)hipEventDestroy(g_prof.ev[i]);
+    delete[] g_prof.ev;
+    g_prof = Profile();
+    return 0;
+}
+
+
+int mustafar_counter_add(void* stream, int32_t* counter, int delta)
+{
+    if (!counter) return MUSTAFAR_EINVAL;
+    counter_add_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(counter, delta);
     return (int)hipGetLastError();
 }
 

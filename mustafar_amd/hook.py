@@ -14,7 +14,10 @@ compressed_length, kv_seq_len) (:445), k_compressed = [bitmaps, idxs, nzs(list p
 `api="reference"` issues exactly the reference's calls (query/probabilities zero-padded to 8 rows :273/:313,
 `torch.cat` of the per-head streams on every call :274/:314, 8-row outputs sliced to row 0 :275/:315).
 `api="native"` calls the same two entry points un-padded (N = 1) and keeps the packed stream of all heads in
-one flat tensor beside the list, so nothing is re-copied per step.  Both produce the same attention output.
+one flat tensor beside the list, so nothing is re-copied per step.
+`api="fused"` replaces the PyTorch glue between the two SpMVs by `mustafar_decode_attention` (C ABI extension):
+the local window lives in a preallocated buffer that is appended in place, and one call per layer launches
+key SpMV -> window scores + softmax -> value SpMV -> combine + window p.V.  All three produce the same output.
 """
 from __future__ import annotations
 
@@ -25,7 +28,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn.functional as F
 
-from . import compression, mustafar_package
+from . import _lib, compression, mustafar_package
 
 
 @dataclass
@@ -37,7 +40,7 @@ class MustafarConfig:
     v_sparsity: float = 0.7
     residual_length: int = 32     # mem_spd_test.py:9, :22
     group_size: int = 32          # carried by the reference config, unused on the kernel path
-    api: str = "native"           # "reference" | "native"
+    api: str = "native"           # "reference" | "native" | "fused"
 
 
 def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:
@@ -96,6 +99,40 @@ def append_compressed(old: list, new: list, heads: int, old_tokens: int, new_tok
     return [bmp, idx, FlatStreams(per_head), off]
 
 
+class Window:
+    """Dense local window with spare capacity: `buf` [B, Hkv, cap, D], the first `len` rows are valid (api="fused")."""
+
+    def __init__(self, tensor: torch.Tensor, cap: int):
+        B, H, w, D = tensor.shape
+        self.buf = torch.empty((B, H, max(cap, w), D), dtype=tensor.dtype, device=tensor.device)
+        self.buf[:, :, :w] = tensor
+        self.len = w
+
+    @property
+    def cap(self) -> int:
+        return self.buf.shape[2]
+
+    def view(self) -> torch.Tensor:
+        return self.buf[:, :, :self.len]
+
+    def reserve(self, n: int):
+        if n > self.cap:
+            nb = torch.empty((self.buf.shape[0], self.buf.shape[1], n + 64, self.buf.shape[3]), dtype=self.buf.dtype,
+                             device=self.buf.device)
+            nb[:, :, :self.len] = self.buf[:, :, :self.len]
+            self.buf = nb
+
+    def drop_front(self, n: int):
+        keep = self.buf[:, :, n:self.len].clone()
+        self.len -= n
+        self.buf[:, :, :self.len] = keep
+
+    def clone(self) -> "Window":
+        w = Window.__new__(Window)
+        w.buf, w.len = self.buf.clone(), self.len
+        return w
+
+
 class MustafarAttention:
     """Prefill + decode attention over the Mustafar cache (no projections, no RoPE: q/k/v arrive post-RoPE)."""
 
@@ -144,10 +181,93 @@ class MustafarAttention:
             repeat_kv(value_states, self.num_key_value_groups), is_causal=True)
         return attn_output, self.build_cache(key_states, value_states)
 
+    # ---- fused decode (extension) ---------------------------------------------------------------------------
+    def to_fused(self, past):
+        """Wrap the two local windows of a reference-layout `past` into appendable buffers."""
+        k_c, k_w, v_c, v_w, C, L = past
+        if isinstance(k_w, Window):
+            return past
+        cap = self.cfg.residual_length + 256 + 64
+        return (k_c, Window(k_w, cap), v_c, Window(v_w, cap), C, L)
+
+    @staticmethod
+    def advance(past, n: int):
+        """Account on the host for `n` graph replays of a decode_fused(step_counter=...) call."""
+        k_c, k_w, v_c, v_w, C, L = past
+        k_w.len += n
+        v_w.len += n
+        return (k_c, k_w, v_c, v_w, C, L + n)
+
+    def _scratch(self, device, BH, ld, ws_bytes):
+        sc = getattr(self, "_scores", None)
+        if sc is None or sc.device != device or sc.numel() < BH * ld:
+            self._scores = torch.empty(BH * ld, dtype=torch.float16, device=device)
+        ws = getattr(self, "_ws_fused", None)
+        if ws is None or ws.device != device or ws.numel() < ws_bytes:
+            self._ws_fused = torch.empty(max(ws_bytes, 1 << 20), dtype=torch.uint8, device=device)
+        return self._scores, self._ws_fused
+
+    def decode_fused(self, query_states, key_states, value_states, past, step_counter: Optional[torch.Tensor] = None):
+        """Same contract as decode() with api="native"; windows are `Window` objects appended in place.
+
+        `step_counter` (int32 device tensor, optional) is added to the window length inside the kernels, so that a
+        captured graph of this call can be replayed for consecutive steps (advance it with mustafar_counter_add once
+        per step); the host-side lengths/`kv_seq_len` of the returned `past` then describe the FIRST replay and the
+        256-token trigger is the caller's business (see bench.py)."""
+        cfg = self.cfg
+        bsz, _, q_len, D = query_states.shape
+        assert q_len == 1 and D == 128
+        BH, Bkv, groups = bsz * self.num_heads, bsz * self.num_key_value_heads, self.num_key_value_groups
+        k_c, k_w, v_c, v_w, C, _ = self.to_fused(past)
+        kv_seq_len = past[-1] + 1
+        w_len = k_w.len + 1
+        k_w.reserve(w_len)
+        v_w.reserve(w_len)
+        dev = query_states.device
+        L = _lib.load()
+        split = L.mustafar_value_pick_split_k(128, 1, C, BH, groups) if C else 1
+        ld = (C + max(k_w.cap, v_w.cap) + 7) // 8 * 8
+        scores, ws = self._scratch(dev, BH, ld, L.mustafar_decode_workspace_bytes(C, BH, groups, split))
+        out = torch.empty((bsz, self.num_heads, 1, D), dtype=torch.float16, device=dev)
+        q = query_states if query_states.is_contiguous() else query_states.contiguous()
+        kn = key_states if key_states.is_contiguous() else key_states.contiguous()
+        vn = value_states if value_states.is_contiguous() else value_states.contiguous()
+        if k_w.cap != v_w.cap:
+            raise RuntimeError("key/value windows must have the same capacity")
+        p = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            err = L.mustafar_decode_attention(
+                torch.cuda.current_stream(dev).cuda_stream,
+                p(k_c[0]) if C else None, p(k_c[2].flat) if C else None, p(k_c[1]) if C else None, p(k_c[3]) if C else None,
+                p(v_c[0]) if C else None, p(v_c[2].flat) if C else None, p(v_c[1]) if C else None, p(v_c[3]) if C else None,
+                q.data_ptr(), k_w.buf.data_ptr(), v_w.buf.data_ptr(), kn.data_ptr(), vn.data_ptr(), w_len, k_w.cap,
+                scores.data_ptr(), ld, out.data_ptr(), ws.data_ptr(), split, C, BH, groups, math.sqrt(D),
+                step_counter.data_ptr() if step_counter is not None else None)
+        _lib.check(err, "mustafar_decode_attention")
+        if step_counter is not None:
+            return out, (k_c, k_w, v_c, v_w, C, kv_seq_len - 1)   # lengths advance with the device counter
+        k_w.len = v_w.len = w_len
+        if (kv_seq_len - cfg.residual_length - C) % 256 == 0 and w_len >= 256:                          # :324
+            k_new = _compress(self.dh_prune_key(k_w.buf[:, :, :256, :]).reshape(Bkv, -1, D), "key")     # :325-340
+            v_new = _compress(self.dh_prune_value(v_w.buf[:, :, :256, :]).reshape(Bkv, -1, D), "value")
+            if C == 0:
+                k_c, v_c = k_new, v_new
+            else:
+                k_c = append_compressed(k_c, k_new, Bkv, C, 256, D)
+                v_c = append_compressed(v_c, v_new, Bkv, C, 256, D)
+            k_w.drop_front(256)                                                                         # :392-393
+            v_w.drop_front(256)
+            C += 256
+        return out, (k_c, k_w, v_c, v_w, C, kv_seq_len)
+
     # ---- decode (model :256-400) -----------------------------------------------------------------------------
     def decode(self, query_states, key_states, value_states, past, attention_mask=None):
         """q [B,Hq,1,D], new k/v [B,Hkv,1,D] -> (attn_output [B,Hq,1,D], past)."""
         cfg = self.cfg
+        if cfg.api == "fused" and attention_mask is None:
+            return self.decode_fused(query_states, key_states, value_states, past)
+        if isinstance(past[1], Window):   # a fused cache handed to the unfused path
+            past = (past[0], past[1].view(), past[2], past[3].view(), past[4], past[5])
         bsz, _, q_len, D = query_states.shape
         total_batch_size = bsz * self.num_heads
         total_batch_kv = bsz * self.num_key_value_heads

@@ -26,7 +26,7 @@ def _dense_reference(q, K_all, V_all, C, ks, vs, groups):
     return torch.matmul(torch.softmax(s, -1), Vr)
 
 
-@pytest.mark.parametrize("api", ["reference", "native"])
+@pytest.mark.parametrize("api", ["reference", "native", "fused"])
 @pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4)])
 def test_prefill_then_decode_matches_dense(api, hq, hkv):
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
@@ -55,7 +55,8 @@ def test_prefill_then_decode_matches_dense(api, hq, hkv):
             torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
         fired += past[4] != C_before
         assert past[5] == L0 + step + 1
-        assert past[1].shape[2] == past[5] - past[4]
+        wlen = past[1].len if api == "fused" else past[1].shape[2]
+        assert wlen == past[5] - past[4]
     assert fired == 1 and past[4] == 512          # one 256-token trigger crossed (model :324)
     # cache tuple keeps the reference layout (model :445, :332): [bitmaps, idxs, list-of-streams, nz_offset]
     kc = past[0]
@@ -64,11 +65,12 @@ def test_prefill_then_decode_matches_dense(api, hq, hkv):
     assert kc[0].numel() == bsz * hkv * 2 * 512 and kc[1].numel() == bsz * hkv * (2 * 512 + 1)
 
 
-def test_decode_without_compressed_part():
+@pytest.mark.parametrize("api", ["native", "fused"])
+def test_decode_without_compressed_part(api):
     """compressed_length == 0 branch (model :280-282, :318-320): short prompt stays dense until the first trigger."""
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
     torch.manual_seed(1)
-    attn = MustafarAttention(MustafarConfig(num_attention_heads=4, num_key_value_heads=2))
+    attn = MustafarAttention(MustafarConfig(num_attention_heads=4, num_key_value_heads=2, api=api))
     q = torch.randn(1, 4, 40, 128, device=DEV).half()
     k = torch.randn(1, 2, 40, 128, device=DEV).half()
     v = torch.randn(1, 2, 40, 128, device=DEV).half()
@@ -81,3 +83,43 @@ def test_decode_without_compressed_part():
         out, past = attn.decode(qn, kn, vn, past)
         want = _dense_reference(qn, K_all, V_all, 0, 0.7, 0.7, 2)
         torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
+
+
+def test_fused_decode_under_graph_replay():
+    """A captured hipGraph of one fused decode step, replayed while a device counter grows the window."""
+    from mustafar_amd import _lib
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    torch.manual_seed(7)
+    bsz, hq, hkv, D, L0 = 1, 8, 2, 128, 300
+    cfg = MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, k_sparsity=0.7, v_sparsity=0.7, api="fused")
+    attn = MustafarAttention(cfg)
+    K_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    V_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    past = attn.to_fused(attn.build_cache(K_all.clone(), V_all.clone()))
+    q, kn, vn = (torch.zeros(bsz, h, 1, D, device=DEV, dtype=torch.float16) for h in (hq, hkv, hkv))
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib = _lib.load()
+    # warm-up on a private copy (allocates the scratch buffers outside the capture)
+    warm = (past[0], past[1].clone(), past[2], past[3].clone(), past[4], past[5])
+    attn.decode_fused(q, kn, vn, warm)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out, _ = attn.decode_fused(q, kn, vn, past, step_counter=counter)
+        _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream().cuda_stream, counter.data_ptr(), 1), "counter")
+    for step in range(12):
+        qn, k1, v1 = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+        q.copy_(qn); kn.copy_(k1); vn.copy_(v1)
+        K_all, V_all = torch.cat([K_all, k1], 2), torch.cat([V_all, v1], 2)
+        g.replay()
+        want = _dense_reference(qn, K_all, V_all, 256, 0.7, 0.7, hq // hkv)
+        torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
+    assert int(counter.item()) == 12
+    past = attn.advance(past, 12)
+    assert past[1].len == L0 - 256 + 12 and past[5] == L0 + 12
+    torch.testing.assert_close(past[1].view()[:, :, -1], K_all[:, :, -1])
+    # and the eager path continues from the advanced state
+    qn, k1, v1 = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+    K_all, V_all = torch.cat([K_all, k1], 2), torch.cat([V_all, v1], 2)
+    out2, past = attn.decode_fused(qn, k1, v1, past)
+    torch.testing.assert_close(out2.float(), _dense_reference(qn, K_all, V_all, 256, 0.7, 0.7, hq // hkv), rtol=4e-3, atol=2e-3)
