@@ -157,22 +157,11 @@ def main():
     from mustafar_amd import _lib
     lib = _lib.load()
 
+    from mustafar_amd.replicas import timed_region
+
     def bracket(run_steps):
         """barrier + synchronize on both sides, max over ranks (the contract's timed region)."""
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        run_steps()
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        return timed_region(run_steps, dist=dist, device=dev)
 
     def timed(api, steps, warmup):
         """Eager call sequence `api`; per-kernel HIP events are recorded live inside the timed region."""

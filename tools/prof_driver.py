@@ -19,7 +19,9 @@ vcs = [build_cache(Bp, T, s, "value", dev, gen) for _ in range(ncopies)]
 ws = torch.zeros(1, dtype=torch.float16, device=dev)
 q = torch.randn((BH, 1, 128), device=dev, generator=gen).half()
 p = torch.softmax(torch.randn((BH, 1, T), device=dev, generator=gen), -1).half()
+calib = torch.empty(128 << 20, dtype=torch.float16, device=dev).normal_()   # 256 MiB: FETCH_SIZE / WRITE_SIZE calibration
 for i in range(iters):
+    calib_out = calib.clone()
     mp.mustafar_key_formulation(*kcs[i % ncopies], q, T, 128, BH, groups)
     mp.mustafar_value_formulation(*vcs[i % ncopies], p, ws, 128, T, BH, groups)
 torch.cuda.synchronize()
