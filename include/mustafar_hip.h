@@ -116,6 +116,14 @@ int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value
 int mustafar_counter_add(void* stream, int32_t* counter, int delta);
 
 /*
+ * FMA engine of the GQA-4 SpMV kernels: 0 = VALU v_fma_mix_f32 (default; MFMA left off as the north_star asks),
+ * 1 = v_mfma_f32_4x4x4_16B_f16 used as a 4-wide FMA unit (opt-in; also MUSTAFAR_FMA_ENGINE=mfma in the environment).
+ * Same inputs, same outputs (fp32 accumulation either way).
+ */
+int mustafar_set_fma_engine(int engine);
+int mustafar_get_fma_engine(void);
+
+/*
  * Live kernel timing inside mustafar_decode_attention (bench.py roofline leg): HIP events recorded on the launch
  * stream around the key and the value SpMV kernels of up to `max_records` calls.  mustafar_profile_end() waits for
  * the recorded events, returns the average durations in microseconds and releases the events.

@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mustafar_hip.h"
 
@@ -128,6 +129,15 @@ __device__ __forceinline__ void meta_issue(Meta<G>& m, const uint64_t* __restric
                      : "=&s"(m.bm), "=&s"(m.ix), "=&s"(m.c[0])
                      : "s"(bmp), "s"(idx), "s"(cp[0]), "i"(S * 64), "i"(S * 32), "i"(S * 16));
     }
+}
+
+// Ordering point without an instruction: legal right after a wait that already drained the counter.
+template <int G>
+__device__ __forceinline__ void meta_ready(Meta<G>& m)
+{
+    if constexpr (G == 4)      asm volatile("" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]), "+s"(m.c[1]), "+s"(m.c[2]), "+s"(m.c[3]));
+    else if constexpr (G == 2) asm volatile("" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]), "+s"(m.c[1]));
+    else                       asm volatile("" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]));
 }
 
 // Drain the counter; the compiler may read `m` only after this statement.
@@ -245,6 +255,121 @@ __device__ __forceinline__ void chunk32(uint32_t adj, const uint64_t* __restrict
     fma8<G>(cur, g, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Alternative FMA engine (opt-in, MUSTAFAR_FMA_ENGINE=mfma; OFF by default because the north_star rules MFMA out):
+// the rank/gather part is unchanged, but the G = 4 multiply-accumulates of FOUR tiles are issued as ONE
+// v_mfma_f32_4x4x4_16B_f16 -- 16 independent 4x4x4 blocks, block = 4 consecutive lanes.  With
+//   B[k][j] = element of tile k in lane 4*blk + j   (the gathered halfs, packed two per VGPR)
+//   A[i][k] = coefficient of head i for tile k      (lane 4*blk + i reads its head's row from a small LDS table)
+// lane l receives D[i][l % 4] = sum_k A[i][k] * B[k][l % 4] = the four head accumulators of ITS element (layout
+// verified by tools/ubench/mfma4x4_layout.hip).  No dense tile is built and nothing is reshaped into a GEMM; the
+// matrix pipe is used as a 4-wide FMA unit, which takes ~3 of the 7 per-tile VALU issue slots away.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MetaB {         // scalar operands of one step (8 tiles) of the MFMA engine: no coefficients
+    u32x16 bm;
+    u32x8 ix;
+};
+
+template <int S>
+__device__ __forceinline__ void metab_issue(MetaB& m, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx)
+{
+    asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx8 %1, %3, %5"
+                 : "=&s"(m.bm), "=&s"(m.ix)
+                 : "s"(bmp), "s"(idx), "i"(S * 64), "i"(S * 32));
+}
+__device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix)); }
+// Ordering point without an instruction: legal right after a wait that already drained the counter.
+__device__ __forceinline__ void metab_ready(MetaB& m) { asm volatile("" : "+s"(m.bm), "+s"(m.ix)); }
+
+struct GatheredClean {
+    uint32_t t[8];    // gathered halfs, exact zero where the tile has no element in this lane
+    uint64_t a[2];    // A fragments (4 coefficient halfs of this lane's head) for tiles 0-3 and 4-7
+};
+
+#define MUSTAFAR_RANK(j)                                                    \
+    "s_lshl2_add_u32 %[o" #j "], %[o" #j "], %[adj]\n\t"                     \
+    "v_mbcnt_lo_u32_b32 %[x" #j "], %[l" #j "], 0\n\t"                        \
+    "v_mbcnt_hi_u32_b32 %[x" #j "], %[h" #j "], %[x" #j "]\n\t"               \
+    "v_lshl_add_u32 %[x" #j "], %[x" #j "], 1, %[o" #j "]\n\t"                \
+    "v_mov_b32 %[t" #j "], 0\n\t"
+#define MUSTAFAR_MLOAD(j) "s_mov_b64 exec, %[m" #j "]\n\tds_read_u16 %[t" #j "], %[x" #j "]\n\t"
+#define MUSTAFAR_MOPS(j) [m##j] "s"(m##j), [l##j] "s"((uint32_t)m##j), [h##j] "s"((uint32_t)(m##j >> 32))
+
+// COFF: byte offset of the step's first coefficient inside a head's row of the LDS coefficient table.
+template <int COFF>
+__device__ __forceinline__ void gather8_clean(const MetaB& m, uint32_t adj, uint32_t ctab_lane, GatheredClean& g)
+{
+    const uint64_t m0 = __builtin_bitreverse64(m.bm[0] | ((uint64_t)m.bm[1] << 32));
+    const uint64_t m1 = __builtin_bitreverse64(m.bm[2] | ((uint64_t)m.bm[3] << 32));
+    const uint64_t m2 = __builtin_bitreverse64(m.bm[4] | ((uint64_t)m.bm[5] << 32));
+    const uint64_t m3 = __builtin_bitreverse64(m.bm[6] | ((uint64_t)m.bm[7] << 32));
+    const uint64_t m4 = __builtin_bitreverse64(m.bm[8] | ((uint64_t)m.bm[9] << 32));
+    const uint64_t m5 = __builtin_bitreverse64(m.bm[10] | ((uint64_t)m.bm[11] << 32));
+    const uint64_t m6 = __builtin_bitreverse64(m.bm[12] | ((uint64_t)m.bm[13] << 32));
+    const uint64_t m7 = __builtin_bitreverse64(m.bm[14] | ((uint64_t)m.bm[15] << 32));
+    uint32_t o0 = m.ix[0], o1 = m.ix[1], o2 = m.ix[2], o3 = m.ix[3], o4 = m.ix[4], o5 = m.ix[5], o6 = m.ix[6], o7 = m.ix[7];
+    uint32_t x0, x1, x2, x3, x4, x5, x6, x7;
+    asm volatile(MUSTAFAR_RANK(0) MUSTAFAR_RANK(1) MUSTAFAR_RANK(2) MUSTAFAR_RANK(3)
+                 MUSTAFAR_RANK(4) MUSTAFAR_RANK(5) MUSTAFAR_RANK(6) MUSTAFAR_RANK(7)
+                 MUSTAFAR_MLOAD(0) MUSTAFAR_MLOAD(1) MUSTAFAR_MLOAD(2) MUSTAFAR_MLOAD(3)
+                 MUSTAFAR_MLOAD(4) MUSTAFAR_MLOAD(5) MUSTAFAR_MLOAD(6) MUSTAFAR_MLOAD(7)
+                 "s_mov_b64 exec, -1\n\t"
+                 "ds_read_b64 %[a0], %[ct] offset:%[c0]\n\t"
+                 "ds_read_b64 %[a1], %[ct] offset:%[c1]"
+                 : [t0] "=&v"(g.t[0]), [t1] "=&v"(g.t[1]), [t2] "=&v"(g.t[2]), [t3] "=&v"(g.t[3]), [t4] "=&v"(g.t[4]),
+                   [t5] "=&v"(g.t[5]), [t6] "=&v"(g.t[6]), [t7] "=&v"(g.t[7]), [a0] "=&v"(g.a[0]), [a1] "=&v"(g.a[1]),
+                   [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5),
+                   [x6] "=&v"(x6), [x7] "=&v"(x7), [o0] "+s"(o0), [o1] "+s"(o1), [o2] "+s"(o2), [o3] "+s"(o3),
+                   [o4] "+s"(o4), [o5] "+s"(o5), [o6] "+s"(o6), [o7] "+s"(o7)
+                 : MUSTAFAR_MOPS(0), MUSTAFAR_MOPS(1), MUSTAFAR_MOPS(2), MUSTAFAR_MOPS(3), MUSTAFAR_MOPS(4), MUSTAFAR_MOPS(5),
+                   MUSTAFAR_MOPS(6), MUSTAFAR_MOPS(7), [adj] "s"(adj), [ct] "v"(ctab_lane), [c0] "i"(COFF), [c1] "i"(COFF + 8)
+                 : "scc");
+}
+
+__device__ __forceinline__ void gatherc_wait(GatheredClean& g)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]),
+                   "+v"(g.t[7]), "+v"(g.a[0]), "+v"(g.a[1]));
+}
+
+__device__ __forceinline__ h16x4 pack4(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3)
+{
+    const uint2 u = {t0 | (t1 << 16), t2 | (t3 << 16)};
+    return __builtin_bit_cast(h16x4, u);
+}
+
+__device__ __forceinline__ void fma8_mfma(const GatheredClean& g, f32x4& acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, g.a[0]), pack4(g.t[0], g.t[1], g.t[2], g.t[3]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, g.a[1]), pack4(g.t[4], g.t[5], g.t[6], g.t[7]), acc, 0, 0, 0);
+}
+
+// One staged chunk (32 tiles) on the MFMA engine; CBASE = byte offset of the chunk's first coefficient in a table row.
+template <int CBASE>
+__device__ __forceinline__ void chunk32_mfma(uint32_t adj, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx,
+                                             uint32_t ctab_lane, f32x4& acc)
+{
+    MetaB cur, nxt;
+    GatheredClean g;
+    metab_issue<0>(cur, bmp, idx);
+    metab_wait(cur);
+#define MUSTAFAR_STEP(S)                               \
+    metab_issue<S + 1>(nxt, bmp, idx);                 \
+    gather8_clean<CBASE + S * 16>(cur, adj, ctab_lane, g); \
+    gatherc_wait(g);                                   \
+    metab_ready(nxt);                                  \
+    fma8_mfma(g, acc);                                 \
+    cur = nxt;
+    MUSTAFAR_STEP(0) MUSTAFAR_STEP(1) MUSTAFAR_STEP(2)
+#undef MUSTAFAR_STEP
+    gather8_clean<CBASE + 48>(cur, adj, ctab_lane, g);
+    gatherc_wait(g);
+    fma8_mfma(g, acc);
+}
+
 __device__ __forceinline__ uint32_t nzbits(uint4 v)
 {
     return (v.x | v.y | v.z | v.w) & 0x7fff7fffu;   // -0.0 counts as zero
@@ -303,12 +428,13 @@ __device__ __forceinline__ uint32_t prefetch_meta(const uint64_t* __restrict__ b
 __device__ __forceinline__ void prefetch_done(uint32_t v) { asm volatile("" ::"v"(v)); }
 
 // One 64-token block against coefficient row `qw` (head stride `chead` pairs) -> acc[h] for lane = token.
-template <int G>
+template <int G, bool MF>
 __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off,
                                            const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
                                            const unsigned char* __restrict__ nz_h, const h16x2* __restrict__ qw,
-                                           uint32_t chead, int lane, float (&acc)[G])
+                                           uint32_t chead, int lane, float (&acc)[G], uint32_t ctab_lane)
 {
+    f32x4 accv = {0.f, 0.f, 0.f, 0.f};   // MFMA engine: the four head accumulators as one register quad
     unsigned char* lds = smem + lds_off;
     const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);   // low half of a flat LDS pointer = LDS offset
     const uint32_t pf = prefetch_meta<0>(bmp_t, idx_t, qw, chead, lane);
@@ -330,7 +456,14 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
 #pragma unroll
             for (int h = 0; h < G; h++) cp[h] = qw + h * chead + c * (kChunkTiles / 2);
             const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
-            chunk32<G>(adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cp, acc);
+            if constexpr (MF && G == 4) {
+                if (c == 0)      chunk32_mfma<0>(adj, bmp_t, idx_t, ctab_lane, accv);
+                else if (c == 1) chunk32_mfma<64>(adj, bmp_t + kChunkTiles, idx_t + kChunkTiles, ctab_lane, accv);
+                else if (c == 2) chunk32_mfma<128>(adj, bmp_t + 2 * kChunkTiles, idx_t + 2 * kChunkTiles, ctab_lane, accv);
+                else             chunk32_mfma<192>(adj, bmp_t + 3 * kChunkTiles, idx_t + 3 * kChunkTiles, ctab_lane, accv);
+            } else {
+                chunk32<G>(adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cp, acc);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (c < 3) {
@@ -338,16 +471,21 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
             i0 = n0;
         }
     }
+    if constexpr (MF && G == 4) {
+#pragma unroll
+        for (int h = 0; h < 4; h++) acc[h] = accv[h];
+    }
 }
 
 // grid: x = ceil(T/256) token super-blocks, y = kv-heads * (groups / G)
-template <int G>
+template <int G, bool MF>
 __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int N, int groups,
     int ldc)   // ldc: row stride of `out` in halfs (T for the reference layout)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16];
+    constexpr int kTabBytes = (MF && G == 4) ? 4 * kD * 2 : 0;   // MFMA engine: q rows of the 4 heads
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16 + kTabBytes];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hb_per_kv = groups / G;
@@ -368,14 +506,26 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
 
     const int tok0 = blockIdx.x * kWaves * 64;
     const int ntok = min(kWaves * 64, T - tok0);
+    uint32_t ctab_lane = 0;
     for (int n = 0; n < N; n++) {
+        if constexpr (MF && G == 4) {
+            if ((rows >> n) & 1u) {   // coefficient table: row n of the 4 heads, 16 bytes per thread
+                unsigned char* tab = smem + kWaves * kStageBytes + 16;
+                __syncthreads();
+                if (threadIdx.x < 64)
+                    reinterpret_cast<uint4*>(tab)[threadIdx.x] =
+                        *reinterpret_cast<const uint4*>(q + ((int64_t)(bh0 + (threadIdx.x >> 4)) * N + n) * kD + (threadIdx.x & 15) * 8);
+                __syncthreads();
+                ctab_lane = (uint32_t)reinterpret_cast<uintptr_t>(tab) + (lane & 3) * (kD * 2);
+            }
+        }
         if ((rows >> n) & 1u) {
             if (tb < ntb) {
                 float acc[G];
 #pragma unroll
                 for (int h = 0; h < G; h++) acc[h] = 0.f;
                 const h16x2* qw = reinterpret_cast<const h16x2*>(q + ((int64_t)bh0 * N + n) * kD);
-                key_tokblk<G>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc);
+                key_tokblk<G, MF>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc, ctab_lane);
 #pragma unroll
                 for (int h = 0; h < G; h++)
                     out[((int64_t)(bh0 + h) * N + n) * ldc + (int64_t)tb * 64 + lane] = (h16)acc[h];
@@ -394,16 +544,30 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
 // ------------------------------------------------------------------------------------------------ value
 // Accumulate token blocks tb_first, tb_first+4, ... < tb_end of one kv-head: lane = channel,
 // acc0 = channels 0..63, acc1 = channels 64..127, coefficient row `pw` (head stride `chead` pairs).
-template <int G>
+template <int G, bool MF>
 __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_off,
                                               const uint64_t* __restrict__ bmp_h, const uint32_t* __restrict__ idx_h,
                                               const unsigned char* __restrict__ nz_h, const h16x2* __restrict__ pw,
                                               uint32_t chead, int tb_first, int tb_end, int lane,
-                                              float (&acc0)[G], float (&acc1)[G])
+                                              float (&acc0)[G], float (&acc1)[G], unsigned char* ptab)
 {
     if (tb_first >= tb_end) return;
     unsigned char* lds = smem + lds_off;
     const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    // MFMA engine: per-wave coefficient table [4 heads][64 tokens] of the current token block (512 B), filled by
+    // lanes 0..31 (16 B each) one token block ahead; lane l reads the row of head l % 4.
+    f32x4 accv0 = {0.f, 0.f, 0.f, 0.f}, accv1 = {0.f, 0.f, 0.f, 0.f};
+    uint32_t ctab_lane = 0;
+    uint4 ptv = {0u, 0u, 0u, 0u};
+    auto ptab_load = [&](int tb) -> uint4 {
+        const h16* src = reinterpret_cast<const h16*>(pw) + (int64_t)((lane >> 3) & 3) * chead * 2 + (int64_t)tb * 64 + (lane & 7) * 8;
+        return *reinterpret_cast<const uint4*>(src);
+    };
+    if constexpr (MF && G == 4) {
+        ctab_lane = (uint32_t)reinterpret_cast<uintptr_t>(ptab) + (lane & 3) * 128;
+        ptv = ptab_load(tb_first);
+        if (lane < 32) reinterpret_cast<uint4*>(ptab)[lane] = ptv;
+    }
     uint32_t pf = prefetch_meta<G>(bmp_h + (int64_t)tb_first * kTilesPerTb, idx_h + (int64_t)tb_first * kTilesPerTb,
                                    pw + (uint32_t)tb_first * 32u, chead, lane);
     uint32_t bnd = bnd_load(idx_h + (int64_t)tb_first * kTilesPerTb, lane);
@@ -420,6 +584,7 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
         pf = prefetch_meta<G>(bmp_h + (int64_t)tbn * kTilesPerTb, idx_h + (int64_t)tbn * kTilesPerTb,
                               pw + (uint32_t)tbn * 32u, chead, lane);
         const uint32_t bnd_next = bnd_load(more ? idx_t + kWaves * kTilesPerTb : idx_t, lane);
+        if constexpr (MF && G == 4) ptv = ptab_load(tbn);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             uint32_t n0 = 0;
@@ -435,29 +600,48 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
 #pragma unroll
             for (int h = 0; h < G; h++) cp[h] = pw + h * chead + ((uint32_t)tb * 64u + (c & 1) * 32u) / 2u;
             const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
-            if (c < 2) chunk32<G>(adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cp, acc0);
-            else       chunk32<G>(adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cp, acc1);
+            if constexpr (MF && G == 4) {
+                if (c == 0)      chunk32_mfma<0>(adj, bmp_t, idx_t, ctab_lane, accv0);
+                else if (c == 1) chunk32_mfma<64>(adj, bmp_t + kChunkTiles, idx_t + kChunkTiles, ctab_lane, accv0);
+                else if (c == 2) chunk32_mfma<0>(adj, bmp_t + 2 * kChunkTiles, idx_t + 2 * kChunkTiles, ctab_lane, accv1);
+                else             chunk32_mfma<64>(adj, bmp_t + 3 * kChunkTiles, idx_t + 3 * kChunkTiles, ctab_lane, accv1);
+            } else {
+                if (c < 2) chunk32<G>(adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cp, acc0);
+                else       chunk32<G>(adj, bmp_t + c * kChunkTiles, idx_t + c * kChunkTiles, cp, acc1);
+            }
             __builtin_amdgcn_wave_barrier();
             if (has_next) {
                 stage_commit(lds, st, lane);
                 i0 = n0;
             }
         }
+        if constexpr (MF && G == 4) {
+            if (more && lane < 32) reinterpret_cast<uint4*>(ptab)[lane] = ptv;   // this block's table is dead now
+            __builtin_amdgcn_wave_barrier();
+        }
         bnd = bnd_next;
     }
     prefetch_done(pf);
+    if constexpr (MF && G == 4) {
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            acc0[h] = accv0[h];
+            acc1[h] = accv1[h];
+        }
+    }
 }
 
 // grid: x = Split_K token chunks, y = kv-heads * (groups / G)
 //   direct != 0 (one chunk): fp16 results go straight to `out`;
 //   else fp32 partial slabs ws[(s*BH + bh)*N + n][128] + one row mask per workgroup in `flags`.
-template <int G>
+template <int G, bool MF>
 __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
     uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb)
-{   // ldb: row stride of `p` in halfs (T for the reference layout; must be even)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16];
+{   // ldb: row stride of `p` in halfs (T for the reference layout; must be even, % 8 == 0 for the MFMA engine)
+    constexpr int kTabBytes = (MF && G == 4) ? kWaves * 512 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16 + kTabBytes];
     static_assert(kWaves * kStageBytes >= kWaves * 2 * 4 * 64 * 4, "reduce buffer must fit in the stage area");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -491,8 +675,8 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
         for (int h = 0; h < G; h++) acc0[h] = acc1[h] = 0.f;
         if (live) {
             const h16x2* pw = reinterpret_cast<const h16x2*>(p + ((int64_t)bh0 * N + n) * ldb);
-            value_tokblks<G>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb0 + wave, tb_end, lane, acc0,
-                             acc1);
+            value_tokblks<G, MF>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb0 + wave, tb_end, lane, acc0,
+                                 acc1, smem + kWaves * kStageBytes + 16 + wave * 512);
         }
         __syncthreads();   // every wave is done with its stage window (and with the previous row's sums)
 #pragma unroll
@@ -729,6 +913,19 @@ __global__ __launch_bounds__(256) void value_finish_kernel(
 
 inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : 1; }
 
+// FMA engine of the G = 4 kernels: 0 = VALU (v_fma_mix_f32; default, MFMA left off as the north_star asks),
+// 1 = matrix pipe as a 4-wide FMA unit (v_mfma_f32_4x4x4_16B_f16; opt-in: MUSTAFAR_FMA_ENGINE=mfma or
+// mustafar_set_fma_engine(1)).
+int g_engine = -1;
+inline int fma_engine()
+{
+    if (g_engine < 0) {
+        const char* e = getenv("MUSTAFAR_FMA_ENGINE");
+        g_engine = (e && (e[0] == 'm' || e[0] == 'M' || e[0] == '1')) ? 1 : 0;
+    }
+    return g_engine;
+}
+
 // Optional live timing of the two SpMV kernels inside mustafar_decode_attention (bench.py's roofline leg): HIP
 // events recorded on the launch stream right around each kernel.  Off by default; not thread-safe by design
 // (the hook is single-threaded, mustafar_wrapper.cu holds the GIL throughout as well).
@@ -765,9 +962,12 @@ int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const v
     auto q  = static_cast<const h16*>(B);
     auto o  = static_cast<h16*>(C);
     switch (G) {
-        case 4: key_spmv_kernel<4><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
-        case 2: key_spmv_kernel<2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
-        default: key_spmv_kernel<1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
+        case 4:
+            if (fma_engine()) key_spmv_kernel<4, true><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T);
+            else              key_spmv_kernel<4, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T);
+            break;
+        case 2: key_spmv_kernel<2, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
+        default: key_spmv_kernel<1, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
     }
     return (int)hipGetLastError();
 }
@@ -830,15 +1030,19 @@ int Value_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const
     const dim3 grid(S, gy);
     switch (G) {
         case 4:
-            value_spmv_kernel<4><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
-                                                            Batch_Size, tb_per_wg, direct, T);
+            if (fma_engine() && (T & 7) == 0)
+                value_spmv_kernel<4, true><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
+                                                                      Batch_Size, tb_per_wg, direct, T);
+            else
+                value_spmv_kernel<4, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
+                                                                       Batch_Size, tb_per_wg, direct, T);
             break;
         case 2:
-            value_spmv_kernel<2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
+            value_spmv_kernel<2, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
                                                             Batch_Size, tb_per_wg, direct, T);
             break;
         default:
-            value_spmv_kernel<1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
+            value_spmv_kernel<1, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
                                                             Batch_Size, tb_per_wg, direct, T);
             break;
     }
@@ -881,9 +1085,12 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
         if (prof) prof_mark(st, 0);
         auto nz = static_cast<const unsigned char*>(k_nz);
         switch (G) {
-            case 4: key_spmv_kernel<4><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
-            case 2: key_spmv_kernel<2><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
-            default: key_spmv_kernel<1><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
+            case 4:
+                if (fma_engine()) key_spmv_kernel<4, true><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores);
+                else              key_spmv_kernel<4, false><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores);
+                break;
+            case 2: key_spmv_kernel<2, false><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
+            default: key_spmv_kernel<1, false><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
         }
         if (prof) prof_mark(st, 1);
     }
@@ -901,9 +1108,12 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
         uint32_t* no_flags = nullptr;
         if (prof) prof_mark(st, 2);
         switch (G) {
-            case 4: value_spmv_kernel<4><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
-            case 2: value_spmv_kernel<2><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
-            default: value_spmv_kernel<1><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
+            case 4:
+                if (fma_engine()) value_spmv_kernel<4, true><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores);
+                else              value_spmv_kernel<4, false><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores);
+                break;
+            case 2: value_spmv_kernel<2, false><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
+            default: value_spmv_kernel<1, false><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
         }
         if (prof) { prof_mark(st, 3); g_prof.n++; }
     }
@@ -955,5 +1165,15 @@ int mustafar_counter_add(void* stream, int32_t* counter, int delta)
     counter_add_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(counter, delta);
     return (int)hipGetLastError();
 }
+
+
+int mustafar_set_fma_engine(int engine)
+{
+    if (engine != 0 && engine != 1) return MUSTAFAR_EINVAL;
+    g_engine = engine;
+    return 0;
+}
+
+int mustafar_get_fma_engine(void) { return fma_engine(); }
 
 }  // extern "C"

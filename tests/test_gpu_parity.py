@@ -24,6 +24,16 @@ def pkg():
     return mustafar_package, compression
 
 
+@pytest.fixture(params=["valu", "mfma"], autouse=True)
+def fma_engine(request):
+    """Every test of this module runs on both FMA engines of the GQA-4 kernels."""
+    from mustafar_amd import _lib
+    L = _lib.load()
+    assert L.mustafar_set_fma_engine(1 if request.param == "mfma" else 0) == 0
+    yield request.param
+    L.mustafar_set_fma_engine(0)
+
+
 def _t(a, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     return t.to(DEV) if dtype is None else t.to(DEV, dtype)
