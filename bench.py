@@ -256,6 +256,16 @@ def main():
             others[api] = {"value": round(world * batch * st_ / dt_o, 2), "unit": "tokens/s", "ms_per_step": round(dt_o / st_ * 1e3, 4),
                            "key_call_us": round(ku, 2), "value_call_us": round(vu, 2),
                            "note": (API_NOTE[api] if api != "fused" else API_NOTE[api].split(";")[0] + "; eager (no graph)")}
+    engine_extra = None
+    if not a.no_reference_api and a.api == "fused" and not a.no_graph and Hq // Hkv >= 4 and (Hq // Hkv) % 4 == 0:
+        # opt-in FMA engine (matrix pipe as a 4-wide FMA unit); NOT the headline: the north_star leaves MFMA off
+        _lib.check(lib.mustafar_set_fma_engine(1), "set_fma_engine")
+        st_ = max(2, a.steps // 2)
+        dt_e, (ku, vu, _) = timed_graph(st_, 1)
+        _lib.check(lib.mustafar_set_fma_engine(0), "set_fma_engine")
+        engine_extra = {"value": round(world * batch * st_ / dt_e, 2), "unit": "tokens/s", "ms_per_step": round(dt_e / st_ * 1e3, 4),
+                        "key_kernel_us": round(ku, 2), "value_kernel_us": round(vu, 2),
+                        "note": "same fused call sequence with MUSTAFAR_FMA_ENGINE=mfma (v_mfma_f32_4x4x4_16B_f16 as FMA unit); opt-in, off by default"}
     alloc_peak = torch.cuda.max_memory_allocated(dev)
 
     if rank != 0:
@@ -301,10 +311,11 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": label, "id": a.config, "layers": a.layers, "q_heads": Hq, "kv_heads": Hkv, "head_dim": D,
                    "sparsity": s, "seq_len": L, "compressed_tokens": T, "batch_per_gpu": batch, "residual_length": R,
-                   "api": a.api, "api_note": API_NOTE[a.api], "parallelism": f"replicas x{world}"},
+                   "api": a.api, "api_note": API_NOTE[a.api], "fma_engine": "valu (v_fma_mix_f32; MFMA off)",
+                   "parallelism": f"replicas x{world}"},
         "peak_kv_bytes": int(kv_bytes), "dense_kv_bytes": int(dense_bytes), "kv_compression_ratio": round(dense_bytes / kv_bytes, 3),
         "allocator_peak_bytes": int(alloc_peak),
-        "roofline": roofline, "cpu_baseline": cpu, "other_call_sequences": others,
+        "roofline": roofline, "cpu_baseline": cpu, "other_call_sequences": others, "fma_engine_mfma": engine_extra,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:
