@@ -119,3 +119,22 @@ def test_cache_append_equals_one_shot_compression(which):
         a, _ = orc.key_spmv(cache[0].numpy(), cache[2].flat.numpy(), cache[1].numpy(), cache[3].numpy(), q, 768, D, heads, 1)
         b, _ = orc.key_spmv(want[0].numpy(), want[2].flat.numpy(), want[1].numpy(), want[3].numpy(), q, 768, D, heads, 1)
         assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
+
+
+def test_compiled_extension_exposes_reference_module_surface():
+    """kernel/kernel_wrapper/pybind.cpp:7-10: module `mustafar_package` with exactly these two functions."""
+    import sys
+    dropin = os.path.join(ROOT, "mustafar_amd", "dropin")
+    sys.path.insert(0, dropin)
+    try:
+        import mustafar_package
+        import kernel.compression as compression
+    finally:
+        sys.path.remove(dropin)
+    assert mustafar_package.__file__.endswith(".so")
+    assert callable(mustafar_package.mustafar_key_formulation) and callable(mustafar_package.mustafar_value_formulation)
+    assert callable(compression.convert_key_batched) and callable(compression.convert_value_batched)
+    bmp = torch.zeros(4, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="Tensor B must be of type float16"):
+        mustafar_package.mustafar_key_formulation(bmp, torch.zeros(8, dtype=torch.float16), torch.zeros(5, dtype=torch.int32),
+                                                  torch.zeros(1, dtype=torch.int32), torch.zeros((1, 8, 128)), 64, 128, 1, 1)
