@@ -110,12 +110,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box: MUSTAFAR_BENCH_REHEARSE=1 puts every rank on cuda:0 and lines them up over gloo
+    rehearse = os.environ.get("MUSTAFAR_BENCH_REHEARSE") == "1"
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist   # RCCL; used only for the barrier and the max-over-ranks of the time
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from mustafar_amd import mustafar_package as mp
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
@@ -161,7 +166,7 @@ def main():
 
     def bracket(run_steps):
         """barrier + synchronize on both sides, max over ranks (the contract's timed region)."""
-        return timed_region(run_steps, dist=dist, device=dev)
+        return timed_region(run_steps, dist=dist, device=dev, reduce_on_cpu=rehearse)
 
     def timed(api, steps, warmup):
         """Eager call sequence `api`; per-kernel HIP events are recorded live inside the timed region."""

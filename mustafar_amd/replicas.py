@@ -17,7 +17,7 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def timed_region(run: Callable[[], None], dist=None, device: Optional[torch.device] = None) -> float:
+def timed_region(run: Callable[[], None], dist=None, device: Optional[torch.device] = None, reduce_on_cpu: bool = False) -> float:
     """barrier + device synchronize on both sides of `run`, then MAX of the elapsed time over all ranks."""
     def sync():
         if device is not None and device.type == "cuda":
@@ -33,7 +33,7 @@ def timed_region(run: Callable[[], None], dist=None, device: Optional[torch.devi
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (device is None or reduce_on_cpu) else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
