@@ -428,7 +428,7 @@ __device__ __forceinline__ uint32_t prefetch_meta(const uint64_t* __restrict__ b
 __device__ __forceinline__ void prefetch_done(uint32_t v) { asm volatile("" ::"v"(v)); }
 
 // One 64-token block against coefficient row `qw` (head stride `chead` pairs) -> acc[h] for lane = token.
-template <int G, bool MF>
+template <int G, bool MF, int CB, int CN>   // chunks [CB, CB + CN) of the token block
 __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off,
                                            const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
                                            const unsigned char* __restrict__ nz_h, const h16x2* __restrict__ qw,
@@ -439,14 +439,14 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
     const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);   // low half of a flat LDS pointer = LDS offset
     const uint32_t pf = prefetch_meta<0>(bmp_t, idx_t, qw, chead, lane);
     const uint32_t bnd = bnd_load(idx_t, lane);
-    uint32_t i0 = bnd_get(bnd, 0);
-    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (bnd_get(bnd, 1) - i0), lane);
+    uint32_t i0 = bnd_get(bnd, CB);
+    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (bnd_get(bnd, CB + 1) - i0), lane);
     stage_commit(lds, st, lane);
     prefetch_done(pf);
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = CB; c < CB + CN; c++) {
         uint32_t n0 = 0;
-        if (c < 3) {
+        if (c < CB + CN - 1) {
             n0 = bnd_get(bnd, c + 1);
             st = stage_issue(nz_h + 4ull * n0, 4u * (bnd_get(bnd, c + 2) - n0), lane);
         }
@@ -466,7 +466,7 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (c < 3) {
+        if (c < CB + CN - 1) {
             stage_commit(lds, st, lane);
             i0 = n0;
         }
@@ -477,8 +477,10 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
     }
 }
 
-// grid: x = ceil(T/256) token super-blocks, y = kv-heads * (groups / G)
-template <int G, bool MF>
+// grid: x = ceil(T/256) token super-blocks (SPLIT = 1: one wave per 64-token block) or ceil(T/128) (SPLIT = 2: two
+// waves per token block, 64 channels each, partial scores folded through LDS -- twice the workgroups, half as long:
+// used when the SPLIT = 1 grid would fit on the chip in a single round), y = kv-heads * (groups / G)
+template <int G, bool MF, int SPLIT>
 __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int N, int groups,
@@ -492,7 +494,9 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     const int kvh = blockIdx.y / hb_per_kv;
     const int bh0 = kvh * groups + (blockIdx.y % hb_per_kv) * G;
     const int ntb = T >> 6;
-    const int tb  = blockIdx.x * kWaves + wave;
+    constexpr int kTbPerWg = kWaves / SPLIT;
+    const int tb  = blockIdx.x * kTbPerWg + wave / SPLIT;
+    const int part = wave % SPLIT;   // which half of the channels this wave covers (SPLIT = 2)
     const int64_t tiles = (int64_t)ntb * kTilesPerTb;
 
     const uint64_t* bmp_t = bmp + (int64_t)kvh * tiles + (int64_t)tb * kTilesPerTb;
@@ -504,8 +508,8 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     if (N > 1)
         rows |= pad_row_mask<G>(q, kD, bh0, N, 0, kD, reinterpret_cast<uint32_t*>(smem + kWaves * kStageBytes));
 
-    const int tok0 = blockIdx.x * kWaves * 64;
-    const int ntok = min(kWaves * 64, T - tok0);
+    const int tok0 = blockIdx.x * kTbPerWg * 64;
+    const int ntok = min(kTbPerWg * 64, T - tok0);
     uint32_t ctab_lane = 0;
     for (int n = 0; n < N; n++) {
         if constexpr (MF && G == 4) {
@@ -520,16 +524,38 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
             }
         }
         if ((rows >> n) & 1u) {
-            if (tb < ntb) {
-                float acc[G];
+            float acc[G];
 #pragma unroll
-                for (int h = 0; h < G; h++) acc[h] = 0.f;
-                const h16x2* qw = reinterpret_cast<const h16x2*>(q + ((int64_t)bh0 * N + n) * kD);
-                key_tokblk<G, MF>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc, ctab_lane);
+            for (int h = 0; h < G; h++) acc[h] = 0.f;
+            const h16x2* qw = reinterpret_cast<const h16x2*>(q + ((int64_t)bh0 * N + n) * kD);
+            if (tb < ntb) {
+                if constexpr (SPLIT == 1) {
+                    key_tokblk<G, MF, 0, 4>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc, ctab_lane);
+                } else {
+                    if (part == 0) key_tokblk<G, MF, 0, 2>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc, ctab_lane);
+                    else           key_tokblk<G, MF, 2, 2>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc, ctab_lane);
+                }
+            }
+            if constexpr (SPLIT == 2) {   // fold the two channel halves: odd wave -> its own (now dead) stage window -> even wave
+                float* fold = reinterpret_cast<float*>(smem + wave * kStageBytes);
+                __syncthreads();
+                if (part == 1) {
+#pragma unroll
+                    for (int h = 0; h < G; h++) fold[h * 64 + lane] = acc[h];
+                }
+                __syncthreads();
+                if (part == 0) {
+                    const float* other = reinterpret_cast<const float*>(smem + (wave + 1) * kStageBytes);
+#pragma unroll
+                    for (int h = 0; h < G; h++) acc[h] += other[h * 64 + lane];
+                }
+            }
+            if (tb < ntb && part == 0) {
 #pragma unroll
                 for (int h = 0; h < G; h++)
                     out[((int64_t)(bh0 + h) * N + n) * ldc + (int64_t)tb * 64 + lane] = (h16)acc[h];
             }
+            if constexpr (SPLIT == 2) __syncthreads();   // the fold buffers are stage windows again in the next row
         } else {   // exact zeros, 16 bytes per lane
             const int per_row = ntok / 8;
             const uint4 z = {0u, 0u, 0u, 0u};
@@ -916,6 +942,17 @@ inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0)
 // FMA engine of the G = 4 kernels: 0 = VALU (v_fma_mix_f32; default, MFMA left off as the north_star asks),
 // 1 = matrix pipe as a 4-wide FMA unit (v_mfma_f32_4x4x4_16B_f16; opt-in: MUSTAFAR_FMA_ENGINE=mfma or
 // mustafar_set_fma_engine(1)).
+int g_key_split = -1;   // 0 = automatic; MUSTAFAR_KEY_SPLIT=1|2 forces
+inline int key_split(int ntb, int gy)
+{
+    if (g_key_split < 0) {
+        const char* e = getenv("MUSTAFAR_KEY_SPLIT");
+        g_key_split = e ? atoi(e) : 0;
+    }
+    if (g_key_split == 1 || g_key_split == 2) return g_key_split;
+    // one wave per token block unless that grid fits on the chip in a single round (256 CUs x 8 workgroups)
+    return ((int64_t)((ntb + kWaves - 1) / kWaves) * gy <= 2048) ? 2 : 1;
+}
 int g_engine = -1;
 inline int fma_engine()
 {
@@ -940,6 +977,32 @@ inline void prof_mark(hipStream_t st, int which)
     if (g_prof.on && g_prof.n < g_prof.cap) (void)hipEventRecord(g_prof.ev[4 * g_prof.n + which], st);
 }
 
+// One place that picks the key kernel instantiation: G heads per pass, FMA engine, waves per token block.
+void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx, const uint32_t* nz_off,
+                const h16* q, h16* out, int T, int N, int groups, int Batch_Size, int ldc)
+{
+    const int G = pick_g(groups);
+    const int gy = (Batch_Size / groups) * (groups / G);
+    const int ntb = T / 64;
+    const int split = key_split(ntb, gy);
+    const int per_wg = kWaves / split;
+    const dim3 grid((ntb + per_wg - 1) / per_wg, gy);
+#define MUSTAFAR_LK(GG, MFF)                                                                                                   \
+    do {                                                                                                                       \
+        if (split == 2) key_spmv_kernel<GG, MFF, 2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, q, out, T, N, groups, ldc); \
+        else            key_spmv_kernel<GG, MFF, 1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, q, out, T, N, groups, ldc); \
+    } while (0)
+    switch (G) {
+        case 4:
+            if (fma_engine()) MUSTAFAR_LK(4, true);
+            else              MUSTAFAR_LK(4, false);
+            break;
+        case 2: MUSTAFAR_LK(2, false); break;
+        default: MUSTAFAR_LK(1, false); break;
+    }
+#undef MUSTAFAR_LK
+}
+
 }  // namespace
 
 extern "C" {
@@ -955,20 +1018,8 @@ int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const v
         Batch_Size < 1 || Batch_Size % groups)
         return MUSTAFAR_EINVAL;
     if (!bmp || !NZ || !idx || !NZ_offset || !B || !C) return MUSTAFAR_EINVAL;
-    const int G = pick_g(groups);
-    const dim3 grid((T / 64 + kWaves - 1) / kWaves, (Batch_Size / groups) * (groups / G));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    auto nz = static_cast<const unsigned char*>(NZ);
-    auto q  = static_cast<const h16*>(B);
-    auto o  = static_cast<h16*>(C);
-    switch (G) {
-        case 4:
-            if (fma_engine()) key_spmv_kernel<4, true><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T);
-            else              key_spmv_kernel<4, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T);
-            break;
-        case 2: key_spmv_kernel<2, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
-        default: key_spmv_kernel<1, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, q, o, T, N, groups, T); break;
-    }
+    launch_key(static_cast<hipStream_t>(stream), bmp, static_cast<const unsigned char*>(NZ), idx, NZ_offset,
+               static_cast<const h16*>(B), static_cast<h16*>(C), T, N, groups, Batch_Size, T);
     return (int)hipGetLastError();
 }
 
@@ -1081,17 +1132,8 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
     int S = 0;
     const bool prof = g_prof.on && g_prof.n < g_prof.cap && T > 0;
     if (T > 0) {
-        const dim3 gk((T / 64 + kWaves - 1) / kWaves, gy);
         if (prof) prof_mark(st, 0);
-        auto nz = static_cast<const unsigned char*>(k_nz);
-        switch (G) {
-            case 4:
-                if (fma_engine()) key_spmv_kernel<4, true><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores);
-                else              key_spmv_kernel<4, false><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores);
-                break;
-            case 2: key_spmv_kernel<2, false><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
-            default: key_spmv_kernel<1, false><<<gk, kThreads, 0, st>>>(k_bmp, nz, k_idx, k_nz_offset, qh, sc, T, 1, groups, ld_scores); break;
-        }
+        launch_key(st, k_bmp, static_cast<const unsigned char*>(k_nz), k_idx, k_nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores);
         if (prof) prof_mark(st, 1);
     }
     window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, static_cast<h16*>(k_window), static_cast<const h16*>(k_new), sc,
