@@ -825,19 +825,27 @@ __global__ __launch_bounds__(kGlueThreads) void window_softmax_kernel(
     const h16* knew = k_new ? k_new + (int64_t)kvh * kD : nullptr;
     if (knew && bh % groups == 0 && tid < 16)   // the group's first head stores the new key row (:270)
         reinterpret_cast<uint4*>(k_win + ((int64_t)kvh * w_cap + (w_len - 1)) * kD)[tid] = reinterpret_cast<const uint4*>(knew)[tid];
-    for (int w0 = 0; w0 < w_len; w0 += kGlueThreads / 16) {
-        const int w = w0 + grp;
-        float sdot = 0.f;
-        if (w < w_len) {
-            const h16* kr = (knew && w == w_len - 1) ? knew : k_win + ((int64_t)kvh * w_cap + w) * kD;
-            Vec8 kv;
-            kv.u = reinterpret_cast<const uint4*>(kr)[sub];
+    // 4 sweeps (128 tokens) per iteration with all four row loads issued before any is used: the loop is a chain of
+    // L2 round trips otherwise
+    constexpr int kSweep = kGlueThreads / 16;
+    for (int w0 = 0; w0 < w_len; w0 += 4 * kSweep) {
+        Vec8 kv[4];
 #pragma unroll
-            for (int j = 0; j < 8; j++) sdot = __builtin_fmaf((float)qv.h[j], (float)kv.h[j], sdot);
+        for (int u = 0; u < 4; u++) {
+            const int w = w0 + u * kSweep + grp;
+            const h16* kr = (knew && w == w_len - 1) ? knew : k_win + ((int64_t)kvh * w_cap + min(w, w_len - 1)) * kD;
+            kv[u].u = reinterpret_cast<const uint4*>(kr)[sub];
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o);
-        if (sub == 0 && w < w_len && w < kMaxWindow) wsc[w] = (h16)sdot;
+        for (int u = 0; u < 4; u++) {
+            const int w = w0 + u * kSweep + grp;
+            float sdot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) sdot = __builtin_fmaf((float)qv.h[j], (float)kv[u].h[j], sdot);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o);
+            if (sub == 0 && w < w_len && w < kMaxWindow) wsc[w] = (h16)sdot;
+        }
     }
     __syncthreads();
 
