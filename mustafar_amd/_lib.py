@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmustafar_hip.so")
+# MUSTAFAR_HIP_LIB points at another build of the same ABI (e.g. the wave-trace build of tools/wave_trace.py)
+LIB_PATH = os.environ.get("MUSTAFAR_HIP_LIB") or os.path.join(_HERE, "lib", "libmustafar_hip.so")
 
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 

@@ -33,11 +33,48 @@ namespace {
 
 typedef _Float16 h16;
 
+// Wave timeline (tools/wave_trace.py; only in builds with -DMUSTAFAR_WAVE_TRACE): lane 0 of every SpMV wave records
+// {start, end} of the 100 MHz wall clock, its HW_ID / XCC_ID registers and its grid position (record = 4 x u64).
+#ifdef MUSTAFAR_WAVE_TRACE
+__device__ unsigned long long* g_trace_buf = nullptr;
+__device__ unsigned int g_trace_cap = 0;
+struct WaveTrace {
+    unsigned long long t0;
+    unsigned int kernel;
+    __device__ explicit WaveTrace(unsigned int k) : t0(__builtin_amdgcn_s_memrealtime()), kernel(k) {}
+    __device__ void end() const
+    {
+        if (g_trace_buf == nullptr || (threadIdx.x & 63) != 0) return;
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        // no atomics (32k same-address atomics would serialise the kernel): the slot is the wave's grid position, key
+        // launches in the lower half of the buffer, value launches in the upper half; a later launch overwrites
+        const unsigned int half = g_trace_cap / 2;
+        const unsigned int w = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (w >= half) return;
+        const unsigned int slot = (kernel == 2 ? half : 0u) + w;
+        const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        unsigned long long* r = g_trace_buf + 4ull * slot;
+        r[0] = t0;
+        r[1] = t1;
+        r[2] = ((unsigned long long)xcc << 32) | hw;
+        r[3] = ((unsigned long long)kernel << 56) | ((unsigned long long)(threadIdx.x >> 6) << 48) |
+               ((unsigned long long)blockIdx.y << 24) | blockIdx.x;
+    }
+};
+#define MUSTAFAR_TRACE_BEGIN(k) const WaveTrace wave_trace_(k)
+#define MUSTAFAR_TRACE_END() wave_trace_.end()
+#else
+#define MUSTAFAR_TRACE_BEGIN(k)
+#define MUSTAFAR_TRACE_END()
+#endif
+
 constexpr int kWaves      = 4;                    // waves per workgroup
 constexpr int kThreads    = 64 * kWaves;
 constexpr int kChunkTiles = 32;                   // tiles staged per LDS chunk
 constexpr int kChunkBytes = kChunkTiles * 128;    // worst case: 64 halfs per tile
-constexpr int kStageBytes = kChunkBytes + 128;    // inactive lanes may read up to 126 B past the data
+constexpr int kStageBytes = kChunkBytes;          // lanes whose element is zero may read up to 126 B past the chunk's data: into
+                                                  // the next wave's window or past the workgroup's LDS (reads as 0); never used.
+                                                  // No pad: 4 x 4 KiB = 16 KiB exactly, one LDS allocation granule less per workgroup
 constexpr int kD          = 128;                  // head_dim supported by this build
 constexpr int kTilesPerTb = kD;                   // tiles per 64-token block (both formats)
 
@@ -100,53 +137,42 @@ typedef h16 h16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
-template <int G>
-struct Meta {          // scalar operands of one step (8 tiles) -- all SGPRs
+struct MetaB {         // tile metadata of one step (8 tiles) -- all SGPRs
     u32x16 bm;         // 8 bitmaps (lo, hi dwords)
     u32x8 ix;          // 8 stream offsets (half2 units)
-    u32x4 c[G];        // per head: 8 coefficients (4 dwords of 2 halfs)
 };
 
-// Issue the scalar loads of step S of a chunk (byte offsets are immediates).  Nothing may read `m` before a
-// meta_wait() that follows.
+// Issue the scalar loads of the bitmaps / offsets of step S of a chunk (byte offsets are immediates).  Nothing may
+// read `m` before a metab_wait() that follows.
+template <int S>
+__device__ __forceinline__ void metab_issue(MetaB& m, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx)
+{
+    asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx8 %1, %3, %5"
+                 : "=&s"(m.bm), "=&s"(m.ix)
+                 : "s"(bmp), "s"(idx), "i"(S * 64), "i"(S * 32));
+}
+__device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix)); }
+// Ordering point without an instruction: legal right after a wait that already drained the counter.
+__device__ __forceinline__ void metab_ready(MetaB& m) { asm volatile("" : "+s"(m.bm), "+s"(m.ix)); }
+
+// Coefficients of step S: per head 8 halfs (4 dwords).  ONE buffer: the loads of step S are issued after the FMAs of
+// step S - 1 have issued and land during the gather phase of step S (whose wait drains them too) -- a second buffer
+// for the next step would push the loop past the 102 SGPRs a wave has.  Readable after gather_wait().
 template <int G, int S>
-__device__ __forceinline__ void meta_issue(Meta<G>& m, const uint64_t* __restrict__ bmp,
-                                           const uint32_t* __restrict__ idx, const h16x2* const (&cp)[G])
+__device__ __forceinline__ void coef_issue(u32x4 (&c)[G], const h16x2* const (&cp)[G])
 {
     if constexpr (G == 4) {
-        asm volatile("s_load_dwordx16 %0, %6, %10\n\ts_load_dwordx8 %1, %7, %11\n\t"
-                     "s_load_dwordx4 %2, %8, %12\n\ts_load_dwordx4 %3, %9, %12\n\t"
-                     "s_load_dwordx4 %4, %13, %12\n\ts_load_dwordx4 %5, %14, %12"
-                     : "=&s"(m.bm), "=&s"(m.ix), "=&s"(m.c[0]), "=&s"(m.c[1]), "=&s"(m.c[2]), "=&s"(m.c[3])
-                     : "s"(bmp), "s"(idx), "s"(cp[0]), "s"(cp[1]), "i"(S * 64), "i"(S * 32), "i"(S * 16), "s"(cp[2]), "s"(cp[3]));
+        asm volatile("s_load_dwordx4 %0, %4, %8\n\ts_load_dwordx4 %1, %5, %8\n\t"
+                     "s_load_dwordx4 %2, %6, %8\n\ts_load_dwordx4 %3, %7, %8"
+                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3])
+                     : "s"(cp[0]), "s"(cp[1]), "s"(cp[2]), "s"(cp[3]), "i"(S * 16));
     } else if constexpr (G == 2) {
-        asm volatile("s_load_dwordx16 %0, %4, %8\n\ts_load_dwordx8 %1, %5, %9\n\t"
-                     "s_load_dwordx4 %2, %6, %10\n\ts_load_dwordx4 %3, %7, %10"
-                     : "=&s"(m.bm), "=&s"(m.ix), "=&s"(m.c[0]), "=&s"(m.c[1])
-                     : "s"(bmp), "s"(idx), "s"(cp[0]), "s"(cp[1]), "i"(S * 64), "i"(S * 32), "i"(S * 16));
+        asm volatile("s_load_dwordx4 %0, %2, %4\n\ts_load_dwordx4 %1, %3, %4"
+                     : "=&s"(c[0]), "=&s"(c[1])
+                     : "s"(cp[0]), "s"(cp[1]), "i"(S * 16));
     } else {
-        asm volatile("s_load_dwordx16 %0, %3, %6\n\ts_load_dwordx8 %1, %4, %7\n\ts_load_dwordx4 %2, %5, %8"
-                     : "=&s"(m.bm), "=&s"(m.ix), "=&s"(m.c[0])
-                     : "s"(bmp), "s"(idx), "s"(cp[0]), "i"(S * 64), "i"(S * 32), "i"(S * 16));
+        asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(c[0]) : "s"(cp[0]), "i"(S * 16));
     }
-}
-
-// Ordering point without an instruction: legal right after a wait that already drained the counter.
-template <int G>
-__device__ __forceinline__ void meta_ready(Meta<G>& m)
-{
-    if constexpr (G == 4)      asm volatile("" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]), "+s"(m.c[1]), "+s"(m.c[2]), "+s"(m.c[3]));
-    else if constexpr (G == 2) asm volatile("" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]), "+s"(m.c[1]));
-    else                       asm volatile("" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]));
-}
-
-// Drain the counter; the compiler may read `m` only after this statement.
-template <int G>
-__device__ __forceinline__ void meta_wait(Meta<G>& m)
-{
-    if constexpr (G == 4)      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]), "+s"(m.c[1]), "+s"(m.c[2]), "+s"(m.c[3]));
-    else if constexpr (G == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]), "+s"(m.c[1]));
-    else                       asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix), "+s"(m.c[0]));
 }
 
 struct Gathered {
@@ -164,8 +190,7 @@ struct Gathered {
 
 // Gather the 8 tiles of a step from the wave's LDS window (no wait).
 //   adj = (LDS byte address of the window) - 4 * (stream offset of its first byte)  ->  tile offset = 4*idx + adj
-template <int G>
-__device__ __forceinline__ void gather8(const Meta<G>& m, uint32_t adj, Gathered& g)
+__device__ __forceinline__ void gather8(const MetaB& m, uint32_t adj, Gathered& g)
 {
 #pragma unroll
     for (int j = 0; j < 8; j++) g.m[j] = __builtin_bitreverse64(m.bm[2 * j] | ((uint64_t)m.bm[2 * j + 1] << 32));
@@ -180,10 +205,22 @@ __device__ __forceinline__ void gather8(const Meta<G>& m, uint32_t adj, Gathered
                  : "scc");
 }
 
-__device__ __forceinline__ void gather_wait(Gathered& g)
+// Drains the counter: the gathers AND the coefficient loads issued before them.
+template <int G>
+__device__ __forceinline__ void gather_wait(Gathered& g, u32x4 (&c)[G])
 {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]), "+v"(g.t[7]));
+    if constexpr (G == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]), "+v"(g.t[7]),
+                       "+s"(c[0]), "+s"(c[1]), "+s"(c[2]), "+s"(c[3]));
+    else if constexpr (G == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]), "+v"(g.t[7]),
+                       "+s"(c[0]), "+s"(c[1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]), "+v"(g.t[7]),
+                       "+s"(c[0]));
 }
 
 #define MUSTAFAR_FMA(a, j, c, sel) "v_fma_mix_f32 %[" #a "], %[t" #j "], %[" #c "], %[" #a "] " sel "\n\t"
@@ -199,12 +236,12 @@ __device__ __forceinline__ void gather_wait(Gathered& g)
     [m0] "s"(g.m[0]), [m1] "s"(g.m[1]), [m2] "s"(g.m[2]), [m3] "s"(g.m[3]), [m4] "s"(g.m[4]), [m5] "s"(g.m[5]),      \
     [m6] "s"(g.m[6]), [m7] "s"(g.m[7]), [t0] "v"(g.t[0]), [t1] "v"(g.t[1]), [t2] "v"(g.t[2]), [t3] "v"(g.t[3]),      \
     [t4] "v"(g.t[4]), [t5] "v"(g.t[5]), [t6] "v"(g.t[6]), [t7] "v"(g.t[7])
-#define MUSTAFAR_COPS(h) [c##h##0] "s"(m.c[h][0]), [c##h##1] "s"(m.c[h][1]), [c##h##2] "s"(m.c[h][2]), [c##h##3] "s"(m.c[h][3])
+#define MUSTAFAR_COPS(h) [c##h##0] "s"(c[h][0]), [c##h##1] "s"(c[h][1]), [c##h##2] "s"(c[h][2]), [c##h##3] "s"(c[h][3])
 
 // acc[h] += tile element x coefficient for the 8 gathered tiles.  The FMAs of tile j run under EXEC = its
 // bitmap, so lanes whose element is zero are untouched: no v_cndmask and no clean gather result needed.
 template <int G>
-__device__ __forceinline__ void fma8(const Meta<G>& m, const Gathered& g, float (&acc)[G])
+__device__ __forceinline__ void fma8(const u32x4 (&c)[G], const Gathered& g, float (&acc)[G])
 {
     if constexpr (G == 4) {
         asm volatile(MUSTAFAR_FMA4(0, 0, MUSTAFAR_LO) MUSTAFAR_FMA4(1, 0, MUSTAFAR_HI) MUSTAFAR_FMA4(2, 1, MUSTAFAR_LO)
@@ -228,31 +265,35 @@ __device__ __forceinline__ void fma8(const Meta<G>& m, const Gathered& g, float 
 }
 
 // One staged chunk = 32 tiles = 4 steps of 8.  Per step:
-//   gather(s) -> wait (LDS latency of the last gather) -> issue scalar loads(s+1) -> FMAs(s) -> wait (what is
-//   left of the scalar-load latency) -> gather(s+1) ...
-// i.e. the scalar loads get the whole FMA phase (the only stretch without a wait) to land.
+//   coefficient loads(s) -> gather(s) -> wait (LDS latency of the last gather; the coefficients are in by then) ->
+//   bitmap/offset loads(s+1) -> FMAs(s) -> wait (what is left of the scalar-load latency) -> ...
+// i.e. the big scalar loads get the whole FMA phase (the only stretch without a wait) to land, the small ones the
+// gather phase.
 //   bmp/idx : wave-uniform pointers to the chunk's 32 bitmaps / stream offsets
 //   cp[h]   : coefficient pairs of head h for the chunk's first tile (32 consecutive halfs are used)
 template <int G>
 __device__ __forceinline__ void chunk32(uint32_t adj, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx,
                                         const h16x2* const (&cp)[G], float (&acc)[G])
 {
-    Meta<G> cur, nxt;
+    MetaB cur, nxt;
+    u32x4 c[G];
     Gathered g;
-    meta_issue<G, 0>(cur, bmp, idx, cp);
-    meta_wait<G>(cur);
-#define MUSTAFAR_STEP(S)                        \
-    gather8<G>(cur, adj, g);                    \
-    gather_wait(g);                             \
-    meta_issue<G, S + 1>(nxt, bmp, idx, cp);    \
-    fma8<G>(cur, g, acc);                       \
-    meta_wait<G>(nxt);                          \
+    metab_issue<0>(cur, bmp, idx);
+    coef_issue<G, 0>(c, cp);
+    metab_wait(cur);
+#define MUSTAFAR_STEP(S)                  \
+    gather8(cur, adj, g);                 \
+    gather_wait<G>(g, c);                 \
+    metab_issue<S + 1>(nxt, bmp, idx);    \
+    fma8<G>(c, g, acc);                   \
+    metab_wait(nxt);                      \
+    coef_issue<G, S + 1>(c, cp);          \
     cur = nxt;
     MUSTAFAR_STEP(0) MUSTAFAR_STEP(1) MUSTAFAR_STEP(2)
 #undef MUSTAFAR_STEP
-    gather8<G>(cur, adj, g);
-    gather_wait(g);
-    fma8<G>(cur, g, acc);
+    gather8(cur, adj, g);
+    gather_wait<G>(g, c);
+    fma8<G>(c, g, acc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -266,22 +307,6 @@ __device__ __forceinline__ void chunk32(uint32_t adj, const uint64_t* __restrict
 // matrix pipe is used as a 4-wide FMA unit, which takes ~3 of the 7 per-tile VALU issue slots away.
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct MetaB {         // scalar operands of one step (8 tiles) of the MFMA engine: no coefficients
-    u32x16 bm;
-    u32x8 ix;
-};
-
-template <int S>
-__device__ __forceinline__ void metab_issue(MetaB& m, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx)
-{
-    asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx8 %1, %3, %5"
-                 : "=&s"(m.bm), "=&s"(m.ix)
-                 : "s"(bmp), "s"(idx), "i"(S * 64), "i"(S * 32));
-}
-__device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix)); }
-// Ordering point without an instruction: legal right after a wait that already drained the counter.
-__device__ __forceinline__ void metab_ready(MetaB& m) { asm volatile("" : "+s"(m.bm), "+s"(m.ix)); }
 
 struct GatheredClean {
     uint32_t t[8];    // gathered halfs, exact zero where the tile has no element in this lane
@@ -395,7 +420,9 @@ __device__ __forceinline__ uint32_t pad_row_mask(const h16* __restrict__ dense, 
     }
     if (mine) atomicOr(sh_mask, mine);
     __syncthreads();
-    return *sh_mask;
+    const uint32_t all = *sh_mask;
+    __syncthreads();   // sh_mask lives in the stage area: nobody may stage before everybody has read it
+    return all;
 }
 
 // ------------------------------------------------------------------------------------------------ key
@@ -487,7 +514,8 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     int ldc)   // ldc: row stride of `out` in halfs (T for the reference layout)
 {
     constexpr int kTabBytes = (MF && G == 4) ? 4 * kD * 2 : 0;   // MFMA engine: q rows of the 4 heads
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16 + kTabBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
+    MUSTAFAR_TRACE_BEGIN(1);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hb_per_kv = groups / G;
@@ -506,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
 
     uint32_t rows = 1u;   // bit n: row n has to be computed
     if (N > 1)
-        rows |= pad_row_mask<G>(q, kD, bh0, N, 0, kD, reinterpret_cast<uint32_t*>(smem + kWaves * kStageBytes));
+        rows |= pad_row_mask<G>(q, kD, bh0, N, 0, kD, reinterpret_cast<uint32_t*>(smem));
 
     const int tok0 = blockIdx.x * kTbPerWg * 64;
     const int ntok = min(kTbPerWg * 64, T - tok0);
@@ -514,7 +542,7 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     for (int n = 0; n < N; n++) {
         if constexpr (MF && G == 4) {
             if ((rows >> n) & 1u) {   // coefficient table: row n of the 4 heads, 16 bytes per thread
-                unsigned char* tab = smem + kWaves * kStageBytes + 16;
+                unsigned char* tab = smem + kWaves * kStageBytes;
                 __syncthreads();
                 if (threadIdx.x < 64)
                     reinterpret_cast<uint4*>(tab)[threadIdx.x] =
@@ -565,6 +593,7 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
             }
         }
     }
+    MUSTAFAR_TRACE_END();
 }
 
 // ------------------------------------------------------------------------------------------------ value
@@ -667,7 +696,8 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
     uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb)
 {   // ldb: row stride of `p` in halfs (T for the reference layout; must be even, % 8 == 0 for the MFMA engine)
     constexpr int kTabBytes = (MF && G == 4) ? kWaves * 512 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 16 + kTabBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
+    MUSTAFAR_TRACE_BEGIN(2);
     static_assert(kWaves * kStageBytes >= kWaves * 2 * 4 * 64 * 4, "reduce buffer must fit in the stage area");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -689,7 +719,7 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
     uint32_t rows = 1u;
     if (N > 1) {
         rows |= pad_row_mask<G>(p, ldb, bh0, N, tb0 * 64, (tb_end - tb0) * 64,
-                                reinterpret_cast<uint32_t*>(smem + kWaves * kStageBytes));
+                                reinterpret_cast<uint32_t*>(smem));
         if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + blockIdx.y] = rows;
     }
 
@@ -702,7 +732,7 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
         if (live) {
             const h16x2* pw = reinterpret_cast<const h16x2*>(p + ((int64_t)bh0 * N + n) * ldb);
             value_tokblks<G, MF>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb0 + wave, tb_end, lane, acc0,
-                                 acc1, smem + kWaves * kStageBytes + 16 + wave * 512);
+                                 acc1, smem + kWaves * kStageBytes + wave * 512);
         }
         __syncthreads();   // every wave is done with its stage window (and with the previous row's sums)
 #pragma unroll
@@ -722,6 +752,7 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
         }
         __syncthreads();
     }
+    MUSTAFAR_TRACE_END();
 }
 
 // out[bh, n, c] = fp16( sum_s ws[s, bh, n, c] ), pad rows only from the slabs whose row mask has them.
@@ -958,7 +989,8 @@ inline int key_split(int ntb, int gy)
         g_key_split = e ? atoi(e) : 0;
     }
     if (g_key_split == 1 || g_key_split == 2) return g_key_split;
-    // one wave per token block unless that grid fits on the chip in a single round (256 CUs x 8 workgroups)
+    // One wave per token block unless that grid is small (<= 2048 workgroups; the chip holds 256 CUs x 6 of them, see
+    // tools/wave_trace.py): then a wave's latency chain, not throughput, sets the time, and two waves per block halve it.
     return ((int64_t)((ntb + kWaves - 1) / kWaves) * gy <= 2048) ? 2 : 1;
 }
 int g_engine = -1;
@@ -1225,5 +1257,16 @@ int mustafar_set_fma_engine(int engine)
 }
 
 int mustafar_get_fma_engine(void) { return fma_engine(); }
+
+#ifdef MUSTAFAR_WAVE_TRACE
+// Tool-only (tools/wave_trace.py): records go to `buf` (4 x u64 each, `cap` slots; zero it first).
+int mustafar_trace_set(void* buf, unsigned int cap)
+{
+    unsigned long long* b = static_cast<unsigned long long*>(buf);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &b, sizeof(b)) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cap), &cap, sizeof(cap)) != hipSuccess) return (int)hipGetLastError();
+    return 0;
+}
+#endif
 
 }  // extern "C"

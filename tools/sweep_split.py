@@ -8,7 +8,7 @@ from tools.microbench import CFG, build_cache, timeit
 
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(1)
-for name in sys.argv[1:] or ["c3", "c5"]:
+for name in sys.argv[1:] or ["c3", "c5"]:   # SWEEP_SPLITS=1,2,4 picks the Split_K values (0 = the library's own choice)
     Hq, Hkv, s, L, batch = CFG[name]
     T = ((L - 32) // 256) * 256
     Bp, BH, groups = batch * Hkv, batch * Hq, Hq // Hkv
@@ -24,7 +24,11 @@ for name in sys.argv[1:] or ["c3", "c5"]:
         mp.mustafar_key_formulation(*kcs[state["i"] % ncopies], q, T, 128, BH, groups)
     tk = timeit(runk, 20)
     print(json.dumps(dict(cfg=name, copies=ncopies, key_us=round(tk * 1e6, 1))), flush=True)
-    for sk in [1, 2, 4, 8, 16, 31, 62, 0]:
+    from mustafar_amd import _lib
+    picked = _lib.load().mustafar_value_pick_split_k(128, 1, T, BH, groups)
+    print(json.dumps(dict(cfg=name, picked_split_k=picked)), flush=True)
+    splits = [int(x) for x in os.environ.get("SWEEP_SPLITS", "1,2,4,8,16,31,62,0").split(",")]
+    for sk in splits:
         def runv():
             state["i"] += 1
             mp.mustafar_value_formulation(*vcs[state["i"] % ncopies], p, ws, 128, T, BH, groups, split_k=sk)
