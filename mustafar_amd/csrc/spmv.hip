@@ -412,7 +412,7 @@ __device__ __forceinline__ uint32_t pad_row_mask(const h16* __restrict__ dense, 
     __syncthreads();
     const int per_row = ncols / 8;
     uint32_t mine = 0;
-    for (int u = threadIdx.x; u < G * (N - 1) * per_row; u += kThreads) {
+    for (int u = threadIdx.x; u < G * (N - 1) * per_row; u += blockDim.x) {
         const int hn = u / per_row, k = u % per_row;
         const int h = hn / (N - 1), n = 1 + hn % (N - 1);
         const uint4 v = *reinterpret_cast<const uint4*>(dense + ((int64_t)(bh0 + h) * N + n) * row_len + col0 + k * 8);
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
 // ------------------------------------------------------------------------------------------------ value
 // Accumulate token blocks tb_first, tb_first+4, ... < tb_end of one kv-head: lane = channel,
 // acc0 = channels 0..63, acc1 = channels 64..127, coefficient row `pw` (head stride `chead` pairs).
-template <int G, bool MF>
+template <int G, bool MF, int CB, int CN, int STRIDE>   // chunks [CB, CB + CN) of every STRIDE-th token block
 __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_off,
                                               const uint64_t* __restrict__ bmp_h, const uint32_t* __restrict__ idx_h,
                                               const unsigned char* __restrict__ nz_h, const h16x2* __restrict__ pw,
@@ -626,27 +626,28 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
     uint32_t pf = prefetch_meta<G>(bmp_h + (int64_t)tb_first * kTilesPerTb, idx_h + (int64_t)tb_first * kTilesPerTb,
                                    pw + (uint32_t)tb_first * 32u, chead, lane);
     uint32_t bnd = bnd_load(idx_h + (int64_t)tb_first * kTilesPerTb, lane);
-    uint32_t i0 = bnd_get(bnd, 0);
-    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (bnd_get(bnd, 1) - i0), lane);
+    uint32_t i0 = bnd_get(bnd, CB);
+    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (bnd_get(bnd, CB + 1) - i0), lane);
     stage_commit(lds, st, lane);
-    for (int tb = tb_first; tb < tb_end; tb += kWaves) {
+    for (int tb = tb_first; tb < tb_end; tb += STRIDE) {
         const uint64_t* bmp_t = bmp_h + (int64_t)tb * kTilesPerTb;
         const uint32_t* idx_t = idx_h + (int64_t)tb * kTilesPerTb;
-        const bool more = tb + kWaves < tb_end;
+        const bool more = tb + STRIDE < tb_end;
         prefetch_done(pf);
         // metadata lines and chunk bounds of the wave's next token block, in flight while this one is processed
-        const int tbn = more ? tb + kWaves : tb;
+        const int tbn = more ? tb + STRIDE : tb;
         pf = prefetch_meta<G>(bmp_h + (int64_t)tbn * kTilesPerTb, idx_h + (int64_t)tbn * kTilesPerTb,
                               pw + (uint32_t)tbn * 32u, chead, lane);
-        const uint32_t bnd_next = bnd_load(more ? idx_t + kWaves * kTilesPerTb : idx_t, lane);
+        const uint32_t bnd_next = bnd_load(more ? idx_t + STRIDE * kTilesPerTb : idx_t, lane);
         if constexpr (MF && G == 4) ptv = ptab_load(tbn);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = CB; c < CB + CN; c++) {
             uint32_t n0 = 0;
-            const bool has_next = (c < 3) || more;
+            const bool last = c == CB + CN - 1;
+            const bool has_next = !last || more;
             if (has_next) {
-                n0 = (c < 3) ? bnd_get(bnd, c + 1) : bnd_get(bnd_next, 0);
-                const uint32_t n1 = (c < 3) ? bnd_get(bnd, c + 2) : bnd_get(bnd_next, 1);
+                n0 = !last ? bnd_get(bnd, c + 1) : bnd_get(bnd_next, CB);
+                const uint32_t n1 = !last ? bnd_get(bnd, c + 2) : bnd_get(bnd_next, CB + 1);
                 st = stage_issue(nz_h + 4ull * n0, 4u * (n1 - n0), lane);
             }
             __builtin_amdgcn_wave_barrier();
@@ -686,19 +687,24 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
     }
 }
 
-// grid: x = Split_K token chunks, y = kv-heads * (groups / G)
+// grid: x = Split_K token chunks, y = kv-heads * (groups / G).  NW waves per workgroup, SPLIT of them share a token
+// block (SPLIT = 2: one wave per 64-channel half, i.e. chunks {0,1} / {2,3}; the halves write disjoint accumulators,
+// so the workgroup reduce below needs no change).  The finer grain matters when a wave only gets a few token blocks:
+// the launch is sized to ONE round of resident workgroups (mustafar_value_pick_split_k) and ends when the longest
+// wave does.
 //   direct != 0 (one chunk): fp16 results go straight to `out`;
 //   else fp32 partial slabs ws[(s*BH + bh)*N + n][128] + one row mask per workgroup in `flags`.
-template <int G, bool MF>
-__global__ __launch_bounds__(kThreads) void value_spmv_kernel(
+template <int G, bool MF, int NW, int SPLIT>
+__global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
     uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb)
 {   // ldb: row stride of `p` in halfs (T for the reference layout; must be even, % 8 == 0 for the MFMA engine)
-    constexpr int kTabBytes = (MF && G == 4) ? kWaves * 512 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
+    constexpr int kTabBytes = (MF && G == 4) ? NW * 512 : 0;
+    constexpr int kStride = NW / SPLIT;   // token blocks in flight per workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NW * kStageBytes + kTabBytes];
     MUSTAFAR_TRACE_BEGIN(2);
-    static_assert(kWaves * kStageBytes >= kWaves * 2 * 4 * 64 * 4, "reduce buffer must fit in the stage area");
+    static_assert(NW * kStageBytes >= NW * 2 * 4 * 64 * 4, "reduce buffer must fit in the stage area");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hb_per_kv = groups / G;
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
     const uint64_t* bmp_h = bmp + (int64_t)kvh * tiles;
     const uint32_t* idx_h = idx + (int64_t)kvh * (tiles + 1);
     const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
-    float* red = reinterpret_cast<float*>(smem);   // [kWaves][2*G][64], overlays the stage windows
+    float* red = reinterpret_cast<float*>(smem);   // [NW][2*G][64], overlays the stage windows
     float* ws_slab = ws + (int64_t)blockIdx.x * BH * N * kD;
     const uint32_t chead = (uint32_t)N * ((uint32_t)ldb / 2u);
 
@@ -731,8 +737,14 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
         for (int h = 0; h < G; h++) acc0[h] = acc1[h] = 0.f;
         if (live) {
             const h16x2* pw = reinterpret_cast<const h16x2*>(p + ((int64_t)bh0 * N + n) * ldb);
-            value_tokblks<G, MF>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb0 + wave, tb_end, lane, acc0,
-                                 acc1, smem + kWaves * kStageBytes + wave * 512);
+            unsigned char* ptab = smem + NW * kStageBytes + wave * 512;
+            const int tb_first = tb0 + wave / SPLIT;
+            if constexpr (SPLIT == 1) {
+                value_tokblks<G, MF, 0, 4, kStride>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb_first, tb_end, lane, acc0, acc1, ptab);
+            } else {
+                if (wave % SPLIT == 0) value_tokblks<G, MF, 0, 2, kStride>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb_first, tb_end, lane, acc0, acc1, ptab);
+                else                   value_tokblks<G, MF, 2, 2, kStride>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb_first, tb_end, lane, acc0, acc1, ptab);
+            }
         }
         __syncthreads();   // every wave is done with its stage window (and with the previous row's sums)
 #pragma unroll
@@ -741,10 +753,10 @@ __global__ __launch_bounds__(kThreads) void value_spmv_kernel(
             red[(wave * 2 * G + G + h) * 64 + lane] = acc1[h];
         }
         __syncthreads();
-        for (int o = threadIdx.x; o < 2 * G * 64; o += kThreads) {
+        for (int o = threadIdx.x; o < 2 * G * 64; o += NW * 64) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < kWaves; w++) s += red[w * 2 * G * 64 + o];
+            for (int w = 0; w < NW; w++) s += red[w * 2 * G * 64 + o];
             const int hh = o >> 6, l = o & 63;   // hh = half * G + h
             const int64_t row = (int64_t)(bh0 + hh % G) * N + n;
             if (direct) out[row * kD + (hh / G) * 64 + l] = (h16)s;
@@ -1043,6 +1055,46 @@ void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, co
 #undef MUSTAFAR_LK
 }
 
+// The value kernel's form: 8 waves per workgroup, two per token block (one per 64-channel half) by default;
+// MUSTAFAR_VALUE_SPLIT=1 selects the older 4-wave / one-wave-per-block form.
+constexpr int kValueWaves = 8;
+int g_value_split = -1;
+inline int value_split()
+{
+    if (g_value_split < 0) {
+        const char* e = getenv("MUSTAFAR_VALUE_SPLIT");
+        g_value_split = (e && atoi(e) == 1) ? 1 : 2;
+    }
+    return g_value_split;
+}
+inline int value_tb_stride() { return value_split() == 2 ? kValueWaves / 2 : kWaves; }   // token blocks in flight per workgroup
+
+// One place that picks the value kernel instantiation.
+void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx,
+                  const uint32_t* nz_off, const h16* p, h16* out, float* ws, uint32_t* flags, int T, int N, int groups,
+                  int Batch_Size, int tb_per_wg, int direct, int ldb)
+{
+    const int G = pick_g(groups);
+#define MUSTAFAR_LV(GG, MFF)                                                                                                     \
+    do {                                                                                                                         \
+        if (value_split() == 2)                                                                                                  \
+            value_spmv_kernel<GG, MFF, kValueWaves, 2><<<grid, kValueWaves * 64, 0, st>>>(bmp, nz, idx, nz_off, p, out, ws, flags, T, N, \
+                                                                                          groups, Batch_Size, tb_per_wg, direct, ldb);  \
+        else                                                                                                                     \
+            value_spmv_kernel<GG, MFF, kWaves, 1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups,    \
+                                                                             Batch_Size, tb_per_wg, direct, ldb);                     \
+    } while (0)
+    switch (G) {
+        case 4:
+            if (fma_engine()) MUSTAFAR_LV(4, true);
+            else              MUSTAFAR_LV(4, false);
+            break;
+        case 2: MUSTAFAR_LV(2, false); break;
+        default: MUSTAFAR_LV(1, false); break;
+    }
+#undef MUSTAFAR_LV
+}
+
 }  // namespace
 
 extern "C" {
@@ -1070,15 +1122,14 @@ int mustafar_value_pick_split_k(int M_Global, int N_Global, int K_Global, int Ba
     const int ntb = K_Global / 64;
     const int G = pick_g(num_key_value_groups);
     const int gy = (Batch_Size / num_key_value_groups) * (num_key_value_groups / G);
-    // aim at ~8 workgroups per CU (256 CUs), at least one token block per wave
-    int want = (2048 + gy - 1) / gy;
-    int max_s = (ntb + kWaves - 1) / kWaves;
-    int s = want < 1 ? 1 : want;
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
-    // normalise so that every chunk is non-empty
-    const int tb_per_wg = (ntb + s - 1) / s;
-    return (ntb + tb_per_wg - 1) / tb_per_wg;
+    // ~2048 workgroups (2-3 rounds of what the chip holds: the start-up latency chains of one round hide behind the
+    // steady state of another -- a single exact round measured 10-25 % slower, tools/sweep_split.py), every workgroup
+    // a multiple of the token blocks it keeps in flight so that its waves finish together.
+    const int stride = value_tb_stride();
+    const int want = (2048 + gy - 1) / gy;
+    int tb = (ntb + want - 1) / want;
+    tb = (tb + stride - 1) / stride * stride;
+    return (ntb + tb - 1) / tb;   // normalised: every chunk is non-empty
 }
 
 int64_t mustafar_value_workspace_bytes(int M_Global, int N_Global, int K_Global, int Batch_Size,
@@ -1118,25 +1169,7 @@ int Value_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const
         const int64_t slabs = (int64_t)Split_K * Batch_Size * N * kD * (int64_t)sizeof(float);
         flags = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(Reduction_Workspace) + slabs);
     }
-    const dim3 grid(S, gy);
-    switch (G) {
-        case 4:
-            if (fma_engine() && (T & 7) == 0)
-                value_spmv_kernel<4, true><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
-                                                                      Batch_Size, tb_per_wg, direct, T);
-            else
-                value_spmv_kernel<4, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
-                                                                       Batch_Size, tb_per_wg, direct, T);
-            break;
-        case 2:
-            value_spmv_kernel<2, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
-                                                            Batch_Size, tb_per_wg, direct, T);
-            break;
-        default:
-            value_spmv_kernel<1, false><<<grid, kThreads, 0, st>>>(bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups,
-                                                            Batch_Size, tb_per_wg, direct, T);
-            break;
-    }
+    launch_value(st, dim3(S, gy), bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, T);
     int err = (int)hipGetLastError();
     if (err || direct) return err;
     value_combine_kernel<<<(unsigned)(Batch_Size * N), 256, 0, st>>>(ws, flags, o, Batch_Size, N, S, groups, G);
@@ -1189,14 +1222,7 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
         h16* no_out = nullptr;
         uint32_t* no_flags = nullptr;
         if (prof) prof_mark(st, 2);
-        switch (G) {
-            case 4:
-                if (fma_engine()) value_spmv_kernel<4, true><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores);
-                else              value_spmv_kernel<4, false><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores);
-                break;
-            case 2: value_spmv_kernel<2, false><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
-            default: value_spmv_kernel<1, false><<<gv, kThreads, 0, st>>>(v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores); break;
-        }
+        launch_value(st, gv, v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores);
         if (prof) { prof_mark(st, 3); g_prof.n++; }
     }
     value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S, sc, ld_scores, T, static_cast<h16*>(v_window), static_cast<const h16*>(v_new),
