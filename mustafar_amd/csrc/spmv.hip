@@ -504,6 +504,156 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dense window
+// Window work of the fused decode path.  It depends only on q / p and the dense local window, not on the SpMV results,
+// so it rides along in the two SpMV launches as a few extra workgroups -- the FIRST rows of the grid (blockIdx.y <
+// wa.rows), so that they are dispatched at t = 0 and are long done when the SpMV workgroups finish -- instead of
+// sitting in the two row kernels after them, where it was a chain of L2 round trips on the critical path.
+union Vec8 {
+    uint4 u;
+    h16 h[8];
+};
+
+struct WinArgs {
+    h16* win;             // [B', w_cap, 128] window buffer (nullptr: no window workgroups in this launch)
+    const h16* fresh;     // [B', 128] newest row, stored at row w_len - 1 (or nullptr: already there)
+    const int* w_extra;   // device step counter added to w_len (graph replay), or nullptr
+    int w_len, w_cap;
+    int rows;             // grid rows (blockIdx.y) taken by window workgroups; SpMV rows follow
+    int nchunks;          // window token chunks per (kv-head, head batch)
+};
+
+__device__ __forceinline__ int window_len(const int* w_extra, int w_len, int w_cap)
+{
+    return w_extra ? min(w_len + *w_extra, w_cap) : w_len;
+}
+
+constexpr int kKeyWinChunk   = 64;    // window tokens per key-side window workgroup
+constexpr int kValueWinChunk = 128;   // window tokens per value-side window workgroup (one partial slab each)
+
+// scores[bh0 + h][T + w] = fp16( q[bh0 + h] . K_window[kvh][w] )   (llama_mustafar_kernel.py:270, :278).
+// 256 threads, 64 tokens: 4 threads per token (32 channels = 4 x 16 B each, all loads in flight at once), q rows of
+// the G heads staged in LDS, 2 shuffles to fold.
+template <int G>
+__device__ __forceinline__ void key_window_wg(unsigned char* smem, const h16* __restrict__ q, h16* wa_win,
+                                              const h16* wa_fresh, int w_len, int w_cap, int nchunks,
+                                              h16* __restrict__ scores, int T, int ld, int groups, int task)
+{   // (the WinArgs fields arrive as scalars: a reference to the by-value kernel argument would pin it to a stack slot)
+    const int hb_per_kv = groups / G;
+    const int hb = task / nchunks, chunk = task % nchunks;
+    const int kvh = hb / hb_per_kv, bh0 = kvh * groups + (hb % hb_per_kv) * G;
+    if (chunk * kKeyWinChunk >= w_len) return;   // workgroup-uniform
+    const int tid = threadIdx.x;
+    h16* qs = reinterpret_cast<h16*>(smem);      // [G][128]
+    if (tid < G * 16) reinterpret_cast<uint4*>(qs)[tid] = reinterpret_cast<const uint4*>(q + (int64_t)bh0 * kD)[tid];
+    const int row = tid >> 2, part = tid & 3;
+    const int w = chunk * kKeyWinChunk + row;
+    const bool valid = w < w_len;
+    const int wr = valid ? w : w_len - 1;
+    const h16* fresh = wa_fresh ? wa_fresh + (int64_t)kvh * kD : nullptr;
+    h16* win = wa_win + (int64_t)kvh * w_cap * kD;
+    const h16* kr = ((fresh && wr == w_len - 1) ? fresh : win + (int64_t)wr * kD) + part * 32;
+    Vec8 kv[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) kv[c].u = reinterpret_cast<const uint4*>(kr)[c];
+    if (fresh && valid && w == w_len - 1 && hb % hb_per_kv == 0) {   // store the new key row (:270)
+#pragma unroll
+        for (int c = 0; c < 4; c++) reinterpret_cast<uint4*>(win + (int64_t)w * kD + part * 32)[c] = kv[c].u;
+    }
+    __syncthreads();
+    float acc[G];
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        acc[h] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            Vec8 qv;
+            qv.u = reinterpret_cast<const uint4*>(qs + h * kD + part * 32)[c];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[h] = __builtin_fmaf((float)kv[c].h[j], (float)qv.h[j], acc[h]);
+        }
+        acc[h] += __shfl_xor(acc[h], 1);
+        acc[h] += __shfl_xor(acc[h], 2);
+    }
+    if (part == 0 && valid) {
+#pragma unroll
+        for (int h = 0; h < G; h++) scores[(int64_t)(bh0 + h) * ld + T + w] = (h16)acc[h];
+    }
+}
+
+// slab[bh0 + h][c] = sum over the chunk's window tokens of p[bh0 + h][T + w] * V_window[kvh][w][c]   (:316).
+// NW waves: 16 lanes x 16 bytes per row, NW * 4 rows per sweep, LDS fold; an empty chunk (beyond the current window
+// length) writes zeros so that the finish pass can add every slab blindly.
+template <int G, int NW>
+__device__ __forceinline__ void value_window_wg(unsigned char* smem, const h16* __restrict__ probs, h16* wa_win,
+                                                const h16* wa_fresh, int w_len, int w_cap, int nchunks,
+                                                float* __restrict__ ws, int64_t slab_stride, int slab0, int T, int ld,
+                                                int groups, int task)
+{
+    constexpr int kGrp = NW * 4, kRedLd = kD + 4;
+    static_assert(kGrp * kRedLd * 4 <= NW * kStageBytes, "fold buffer must fit in the stage area");
+    const int hb_per_kv = groups / G;
+    const int hb = task / nchunks, chunk = task % nchunks;
+    const int kvh = hb / hb_per_kv, bh0 = kvh * groups + (hb % hb_per_kv) * G;
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    const int w0 = chunk * kValueWinChunk, w1 = min(w0 + kValueWinChunk, w_len);
+    float* slab = ws + (int64_t)(slab0 + chunk) * slab_stride;
+    float* red = reinterpret_cast<float*>(smem);   // [kGrp][kRedLd]
+    const h16* fresh = wa_fresh ? wa_fresh + (int64_t)kvh * kD : nullptr;
+    h16* win = wa_win + (int64_t)kvh * w_cap * kD;
+    float acc[G][8];
+#pragma unroll
+    for (int h = 0; h < G; h++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[h][j] = 0.f;
+    if (w0 >= w_len) {   // empty chunk: zeros, and out of the way at once
+        for (int o = tid; o < G * kD; o += NW * 64) slab[(int64_t)bh0 * kD + o] = 0.f;
+        return;
+    }
+    // two sweeps per pass, every load of the pass in flight before the first use: the workgroup sits in a slot the
+    // SpMV workgroups are waiting for, so it is written for latency (within the register budget of 6 waves per SIMD)
+    for (int wp = w0 + grp; wp < w1; wp += 2 * kGrp) {
+        Vec8 vv[2];
+        h16 pv[2][G];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int w = wp + u * kGrp;
+            const int wr = w < w1 ? w : w0;
+            const h16* vr = (fresh && wr == w_len - 1) ? fresh : win + (int64_t)wr * kD;
+            vv[u].u = reinterpret_cast<const uint4*>(vr)[sub];
+#pragma unroll
+            for (int h = 0; h < G; h++) pv[u][h] = probs[(int64_t)(bh0 + h) * ld + T + wr];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int w = wp + u * kGrp;
+            if (w < w1) {
+                if (fresh && w == w_len - 1 && hb % hb_per_kv == 0)   // store the new value row (:309)
+                    reinterpret_cast<uint4*>(win + (int64_t)w * kD)[sub] = vv[u].u;
+#pragma unroll
+                for (int h = 0; h < G; h++) {
+                    const float pw = (float)pv[u][h];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[h][j] = __builtin_fmaf(pw, (float)vv[u].h[j], acc[h][j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[grp * kRedLd + sub * 8 + j] = acc[h][j];
+        __syncthreads();
+        if (tid < kD) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < kGrp; g++) sum += red[g * kRedLd + tid];
+            slab[(int64_t)(bh0 + h) * kD + tid] = sum;
+        }
+    }
+}
+
 // grid: x = ceil(T/256) token super-blocks (SPLIT = 1: one wave per 64-token block) or ceil(T/128) (SPLIT = 2: two
 // waves per token block, 64 channels each, partial scores folded through LDS -- twice the workgroups, half as long:
 // used when the SPLIT = 1 grid would fit on the chip in a single round), y = kv-heads * (groups / G)
@@ -511,16 +661,25 @@ template <int G, bool MF, int SPLIT>
 __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int N, int groups,
-    int ldc)   // ldc: row stride of `out` in halfs (T for the reference layout)
+    int ldc, WinArgs wa)   // ldc: row stride of `out` in halfs (T for the reference layout)
 {
     constexpr int kTabBytes = (MF && G == 4) ? 4 * kD * 2 : 0;   // MFMA engine: q rows of the 4 heads
     __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
     MUSTAFAR_TRACE_BEGIN(1);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int)blockIdx.y < wa.rows) {   // fused decode only (N == 1): window scores
+        const int task = blockIdx.y * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wa.rows) * wa.nchunks)
+            key_window_wg<G>(smem, q, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, out, T, ldc,
+                             groups, task);
+        MUSTAFAR_TRACE_END();
+        return;
+    }
+    const int by = blockIdx.y - wa.rows;
     const int hb_per_kv = groups / G;
-    const int kvh = blockIdx.y / hb_per_kv;
-    const int bh0 = kvh * groups + (blockIdx.y % hb_per_kv) * G;
+    const int kvh = by / hb_per_kv;
+    const int bh0 = kvh * groups + (by % hb_per_kv) * G;
     const int ntb = T >> 6;
     constexpr int kTbPerWg = kWaves / SPLIT;
     const int tb  = blockIdx.x * kTbPerWg + wave / SPLIT;
@@ -698,7 +857,7 @@ template <int G, bool MF, int NW, int SPLIT>
 __global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
-    uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb)
+    uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb, WinArgs wa)
 {   // ldb: row stride of `p` in halfs (T for the reference layout; must be even, % 8 == 0 for the MFMA engine)
     constexpr int kTabBytes = (MF && G == 4) ? NW * 512 : 0;
     constexpr int kStride = NW / SPLIT;   // token blocks in flight per workgroup
@@ -707,9 +866,18 @@ __global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
     static_assert(NW * kStageBytes >= NW * 2 * 4 * 64 * 4, "reduce buffer must fit in the stage area");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int)blockIdx.y < wa.rows) {   // fused decode only (N == 1): window p.V -> slabs gridDim.x ..
+        const int task = blockIdx.y * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wa.rows) * wa.nchunks)
+            value_window_wg<G, NW>(smem, p, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, ws,
+                                   (int64_t)BH * kD, gridDim.x, T, ldb, groups, task);
+        MUSTAFAR_TRACE_END();
+        return;
+    }
+    const int by = blockIdx.y - wa.rows;
     const int hb_per_kv = groups / G;
-    const int kvh = blockIdx.y / hb_per_kv;
-    const int bh0 = kvh * groups + (blockIdx.y % hb_per_kv) * G;
+    const int kvh = by / hb_per_kv;
+    const int bh0 = kvh * groups + (by % hb_per_kv) * G;
     const int ntb = T >> 6;
     const int tb0 = blockIdx.x * tb_per_wg;
     const int tb_end = min(ntb, tb0 + tb_per_wg);
@@ -726,7 +894,7 @@ __global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
     if (N > 1) {
         rows |= pad_row_mask<G>(p, ldb, bh0, N, tb0 * 64, (tb_end - tb0) * 64,
                                 reinterpret_cast<uint32_t*>(smem));
-        if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + blockIdx.y] = rows;
+        if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + by] = rows;   // (no window rows when N > 1)
     }
 
     for (int n = 0; n < N; n++) {
@@ -836,11 +1004,6 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh)
 // The quotient is formed as a product with 1/sqrt(d): at most 1 fp32 ulp away before the fp16 rounding.
 __device__ __forceinline__ float scaled(h16 a, float inv_sqrt_d) { return (float)(h16)((float)a * inv_sqrt_d); }
 
-union Vec8 {
-    uint4 u;
-    h16 h[8];
-};
-
 __global__ __launch_bounds__(kGlueThreads) void window_softmax_kernel(
     const h16* __restrict__ q, h16* __restrict__ k_win, const h16* __restrict__ k_new, h16* __restrict__ scores,
     int T, int ld, int w_len, int w_cap, int groups, float inv_sqrt_d, const int* __restrict__ w_extra)
@@ -861,17 +1024,22 @@ __global__ __launch_bounds__(kGlueThreads) void window_softmax_kernel(
         x[i].u = (v < nvec) ? reinterpret_cast<const uint4*>(row)[v] : make_uint4(0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u);  // -inf
     }
 
-    // (2) window scores: 16 lanes per token (8 channels each), 32 tokens per sweep; fp32 accumulate, fp16 result (:278)
+    // (2) window scores: already in the row (computed by the window workgroups of the key SpMV launch) ...
+    if (k_win == nullptr) {
+        for (int w = tid; w < w_len; w += kGlueThreads) wsc[w] = row[T + w];
+        w_len = min(w_len, kMaxWindow);
+    }
+    // ... or computed here: 16 lanes per token (8 channels each), 32 tokens per sweep; fp32 accumulate, fp16 result (:278)
     const int sub = tid & 15, grp = tid >> 4;
     Vec8 qv;
     qv.u = reinterpret_cast<const uint4*>(q + (int64_t)bh * kD)[sub];
     const h16* knew = k_new ? k_new + (int64_t)kvh * kD : nullptr;
-    if (knew && bh % groups == 0 && tid < 16)   // the group's first head stores the new key row (:270)
+    if (k_win && knew && bh % groups == 0 && tid < 16)   // the group's first head stores the new key row (:270)
         reinterpret_cast<uint4*>(k_win + ((int64_t)kvh * w_cap + (w_len - 1)) * kD)[tid] = reinterpret_cast<const uint4*>(knew)[tid];
     // 4 sweeps (128 tokens) per iteration with all four row loads issued before any is used: the loop is a chain of
     // L2 round trips otherwise
     constexpr int kSweep = kGlueThreads / 16;
-    for (int w0 = 0; w0 < w_len; w0 += 4 * kSweep) {
+    for (int w0 = 0; k_win != nullptr && w0 < w_len; w0 += 4 * kSweep) {
         Vec8 kv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -946,8 +1114,9 @@ __global__ __launch_bounds__(256) void value_finish_kernel(
     // window p.V
     const int sub = tid & 15, grp = tid >> 4;
     const h16* vnew = v_new ? v_new + (int64_t)kvh * kD : nullptr;
-    if (vnew && bh % groups == 0 && tid < 16)
+    if (v_win && vnew && bh % groups == 0 && tid < 16)
         reinterpret_cast<uint4*>(v_win + ((int64_t)kvh * w_cap + (w_len - 1)) * kD)[tid] = reinterpret_cast<const uint4*>(vnew)[tid];
+    if (v_win == nullptr) w_len = 0;   // the window p.V arrives as extra slabs (window workgroups of the value SpMV launch)
     const h16* pr = probs + (int64_t)bh * ld + T;
     float acc[8];
 #pragma unroll
@@ -1005,6 +1174,17 @@ inline int key_split(int ntb, int gy)
     // tools/wave_trace.py): then a wave's latency chain, not throughput, sets the time, and two waves per block halve it.
     return ((int64_t)((ntb + kWaves - 1) / kWaves) * gy <= 2048) ? 2 : 1;
 }
+// MUSTAFAR_WINDOW=rows keeps the dense-window work of the fused path inside the softmax / finish row kernels
+// (the form used when T == 0) instead of window workgroups in the SpMV launches.
+int g_window_rows = -1;
+inline bool window_in_row_kernels()
+{
+    if (g_window_rows < 0) {
+        const char* e = getenv("MUSTAFAR_WINDOW");
+        g_window_rows = (e && e[0] == 'r') ? 1 : 0;
+    }
+    return g_window_rows == 1;
+}
 int g_engine = -1;
 inline int fma_engine()
 {
@@ -1031,18 +1211,23 @@ inline void prof_mark(hipStream_t st, int which)
 
 // One place that picks the key kernel instantiation: G heads per pass, FMA engine, waves per token block.
 void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx, const uint32_t* nz_off,
-                const h16* q, h16* out, int T, int N, int groups, int Batch_Size, int ldc)
+                const h16* q, h16* out, int T, int N, int groups, int Batch_Size, int ldc, WinArgs wa = WinArgs{})
 {
     const int G = pick_g(groups);
     const int gy = (Batch_Size / groups) * (groups / G);
     const int ntb = T / 64;
     const int split = key_split(ntb, gy);
     const int per_wg = kWaves / split;
-    const dim3 grid((ntb + per_wg - 1) / per_wg, gy);
+    dim3 grid((ntb + per_wg - 1) / per_wg, gy);
+    if (wa.win) {   // window workgroups first: whole grid rows in front of the SpMV rows
+        wa.nchunks = (wa.w_cap + kKeyWinChunk - 1) / kKeyWinChunk;
+        wa.rows = (gy * wa.nchunks + (int)grid.x - 1) / (int)grid.x;
+        grid.y += wa.rows;
+    }
 #define MUSTAFAR_LK(GG, MFF)                                                                                                   \
     do {                                                                                                                       \
-        if (split == 2) key_spmv_kernel<GG, MFF, 2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, q, out, T, N, groups, ldc); \
-        else            key_spmv_kernel<GG, MFF, 1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, q, out, T, N, groups, ldc); \
+        if (split == 2) key_spmv_kernel<GG, MFF, 2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa); \
+        else            key_spmv_kernel<GG, MFF, 1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa); \
     } while (0)
     switch (G) {
         case 4:
@@ -1072,17 +1257,22 @@ inline int value_tb_stride() { return value_split() == 2 ? kValueWaves / 2 : kWa
 // One place that picks the value kernel instantiation.
 void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx,
                   const uint32_t* nz_off, const h16* p, h16* out, float* ws, uint32_t* flags, int T, int N, int groups,
-                  int Batch_Size, int tb_per_wg, int direct, int ldb)
+                  int Batch_Size, int tb_per_wg, int direct, int ldb, WinArgs wa = WinArgs{})
 {
     const int G = pick_g(groups);
+    if (wa.win) {   // window workgroups first; their partial slabs follow the grid.x token-chunk slabs
+        wa.nchunks = (wa.w_cap + kValueWinChunk - 1) / kValueWinChunk;
+        wa.rows = ((int)grid.y * wa.nchunks + (int)grid.x - 1) / (int)grid.x;
+        grid.y += wa.rows;
+    }
 #define MUSTAFAR_LV(GG, MFF)                                                                                                     \
     do {                                                                                                                         \
         if (value_split() == 2)                                                                                                  \
             value_spmv_kernel<GG, MFF, kValueWaves, 2><<<grid, kValueWaves * 64, 0, st>>>(bmp, nz, idx, nz_off, p, out, ws, flags, T, N, \
-                                                                                          groups, Batch_Size, tb_per_wg, direct, ldb);  \
+                                                                                          groups, Batch_Size, tb_per_wg, direct, ldb, wa);  \
         else                                                                                                                     \
             value_spmv_kernel<GG, MFF, kWaves, 1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups,    \
-                                                                             Batch_Size, tb_per_wg, direct, ldb);                     \
+                                                                             Batch_Size, tb_per_wg, direct, ldb, wa);                     \
     } while (0)
     switch (G) {
         case 4:
@@ -1179,8 +1369,8 @@ int Value_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const
 
 int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value_groups, int Split_K)
 {
-    (void)T; (void)num_key_value_groups;
-    return (int64_t)(Split_K < 1 ? 1 : Split_K) * Batch_Size * kD * (int64_t)sizeof(float);
+    (void)T; (void)num_key_value_groups;   // token-chunk slabs + the window workgroups' partial slabs
+    return (int64_t)((Split_K < 1 ? 1 : Split_K) + kMaxWindow / kValueWinChunk) * Batch_Size * kD * (int64_t)sizeof(float);
 }
 
 int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k_nz, const uint32_t* k_idx,
@@ -1202,14 +1392,22 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
     auto sc = static_cast<h16*>(scores);
     const int G = pick_g(groups);
     const int gy = (Batch_Size / groups) * (groups / G);
-    int S = 0;
+    int S = 0, nwin_slabs = 0;
     const bool prof = g_prof.on && g_prof.n < g_prof.cap && T > 0;
+    auto kwin = static_cast<h16*>(k_window);
+    auto vwin = static_cast<h16*>(v_window);
+    auto knew = static_cast<const h16*>(k_new);
+    auto vnew = static_cast<const h16*>(v_new);
+    // With a compressed part the dense-window work rides in the two SpMV launches (window workgroups); without one
+    // (T == 0) the two row kernels do it themselves.
+    const bool ride = T > 0 && !window_in_row_kernels();
     if (T > 0) {
+        const WinArgs kw = ride ? WinArgs{kwin, knew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
         if (prof) prof_mark(st, 0);
-        launch_key(st, k_bmp, static_cast<const unsigned char*>(k_nz), k_idx, k_nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores);
+        launch_key(st, k_bmp, static_cast<const unsigned char*>(k_nz), k_idx, k_nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores, kw);
         if (prof) prof_mark(st, 1);
     }
-    window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, static_cast<h16*>(k_window), static_cast<const h16*>(k_new), sc,
+    window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride ? nullptr : kwin, ride ? nullptr : knew, sc,
                                                                T, ld_scores, window_len, window_capacity, groups,
                                                                (float)(1.0 / (double)sqrt_d), window_len_extra);
     float* ws = static_cast<float*>(workspace);
@@ -1221,11 +1419,13 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
         auto nz = static_cast<const unsigned char*>(v_nz);
         h16* no_out = nullptr;
         uint32_t* no_flags = nullptr;
+        const WinArgs vw = ride ? WinArgs{vwin, vnew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
+        if (ride) nwin_slabs = (window_capacity + kValueWinChunk - 1) / kValueWinChunk;
         if (prof) prof_mark(st, 2);
-        launch_value(st, gv, v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores);
+        launch_value(st, gv, v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores, vw);
         if (prof) { prof_mark(st, 3); g_prof.n++; }
     }
-    value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S, sc, ld_scores, T, static_cast<h16*>(v_window), static_cast<const h16*>(v_new),
+    value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S + nwin_slabs, sc, ld_scores, T, ride ? nullptr : vwin, ride ? nullptr : vnew,
                                                     window_len, window_capacity, static_cast<h16*>(out), Batch_Size, groups,
                                                     window_len_extra);
     return (int)hipGetLastError();
