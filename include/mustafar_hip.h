@@ -124,9 +124,10 @@ int mustafar_set_fma_engine(int engine);
 int mustafar_get_fma_engine(void);
 
 /*
- * Live kernel timing inside mustafar_decode_attention (bench.py roofline leg): HIP events recorded on the launch
- * stream around the key and the value SpMV kernels of up to `max_records` calls.  mustafar_profile_end() waits for
- * the recorded events, returns the average durations in microseconds and releases the events.
+ * Live kernel timing inside mustafar_decode_attention (bench.py roofline leg): HIP events that receive the start and
+ * stop timestamps of the key and the value SpMV kernels themselves (hipExtLaunchKernel; the same interval rocprofv3
+ * reports) for up to `max_records` calls.  mustafar_profile_end() waits for the recorded events, returns the average
+ * durations in microseconds and releases the events.
  */
 int mustafar_profile_begin(int max_records);
 int mustafar_profile_end(double* key_us_avg, double* value_us_avg, int* records);

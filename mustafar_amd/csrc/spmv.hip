@@ -24,6 +24,7 @@
 // __float2half_rn (SpMM_Kernel.cuh:418, :673).
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1196,7 +1197,7 @@ inline int fma_engine()
 }
 
 // Optional live timing of the two SpMV kernels inside mustafar_decode_attention (bench.py's roofline leg): HIP
-// events recorded on the launch stream right around each kernel.  Off by default; not thread-safe by design
+// events that receive each kernel's own start / stop timestamps (hipExtLaunchKernel), i.e. what rocprofv3 reports.  Off by default; not thread-safe by design
 // (the hook is single-threaded, mustafar_wrapper.cu holds the GIL throughout as well).
 struct Profile {
     bool on = false;
@@ -1204,14 +1205,11 @@ struct Profile {
     hipEvent_t* ev = nullptr;   // 4 per record: key begin/end, value begin/end
 } g_prof;
 
-inline void prof_mark(hipStream_t st, int which)
-{
-    if (g_prof.on && g_prof.n < g_prof.cap) (void)hipEventRecord(g_prof.ev[4 * g_prof.n + which], st);
-}
 
 // One place that picks the key kernel instantiation: G heads per pass, FMA engine, waves per token block.
 void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx, const uint32_t* nz_off,
-                const h16* q, h16* out, int T, int N, int groups, int Batch_Size, int ldc, WinArgs wa = WinArgs{})
+                const h16* q, h16* out, int T, int N, int groups, int Batch_Size, int ldc, WinArgs wa = WinArgs{},
+                hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)   // ev0/ev1: the kernel's own start / stop timestamps
 {
     const int G = pick_g(groups);
     const int gy = (Batch_Size / groups) * (groups / G);
@@ -1226,8 +1224,10 @@ void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, co
     }
 #define MUSTAFAR_LK(GG, MFF)                                                                                                   \
     do {                                                                                                                       \
-        if (split == 2) key_spmv_kernel<GG, MFF, 2><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa); \
-        else            key_spmv_kernel<GG, MFF, 1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa); \
+        if (split == 2) hipExtLaunchKernelGGL((key_spmv_kernel<GG, MFF, 2>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,         \
+                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa);                           \
+        else            hipExtLaunchKernelGGL((key_spmv_kernel<GG, MFF, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,         \
+                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa);                           \
     } while (0)
     switch (G) {
         case 4:
@@ -1248,16 +1248,18 @@ inline int value_split()
 {
     if (g_value_split < 0) {
         const char* e = getenv("MUSTAFAR_VALUE_SPLIT");
-        g_value_split = (e && atoi(e) == 1) ? 1 : 2;
+        g_value_split = e ? (atoi(e) == 1 ? 1 : 2) : 0;
     }
-    return g_value_split;
+    if (g_value_split) return g_value_split;
+    return fma_engine() ? 1 : 2;   // the MFMA form needs > 80 VGPRs: 8-wave workgroups would drop to 4 waves per SIMD
 }
 inline int value_tb_stride() { return value_split() == 2 ? kValueWaves / 2 : kWaves; }   // token blocks in flight per workgroup
 
 // One place that picks the value kernel instantiation.
 void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx,
                   const uint32_t* nz_off, const h16* p, h16* out, float* ws, uint32_t* flags, int T, int N, int groups,
-                  int Batch_Size, int tb_per_wg, int direct, int ldb, WinArgs wa = WinArgs{})
+                  int Batch_Size, int tb_per_wg, int direct, int ldb, WinArgs wa = WinArgs{}, hipEvent_t ev0 = nullptr,
+                  hipEvent_t ev1 = nullptr)
 {
     const int G = pick_g(groups);
     if (wa.win) {   // window workgroups first; their partial slabs follow the grid.x token-chunk slabs
@@ -1265,14 +1267,14 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
         wa.rows = ((int)grid.y * wa.nchunks + (int)grid.x - 1) / (int)grid.x;
         grid.y += wa.rows;
     }
-#define MUSTAFAR_LV(GG, MFF)                                                                                                     \
-    do {                                                                                                                         \
-        if (value_split() == 2)                                                                                                  \
-            value_spmv_kernel<GG, MFF, kValueWaves, 2><<<grid, kValueWaves * 64, 0, st>>>(bmp, nz, idx, nz_off, p, out, ws, flags, T, N, \
-                                                                                          groups, Batch_Size, tb_per_wg, direct, ldb, wa);  \
-        else                                                                                                                     \
-            value_spmv_kernel<GG, MFF, kWaves, 1><<<grid, kThreads, 0, st>>>(bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups,    \
-                                                                             Batch_Size, tb_per_wg, direct, ldb, wa);                     \
+#define MUSTAFAR_LV(GG, MFF)                                                                                                   \
+    do {                                                                                                                       \
+        if (value_split() == 2)                                                                                                \
+            hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kValueWaves, 2>), grid, dim3(kValueWaves * 64), 0, st, ev0, ev1, 0, \
+                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa); \
+        else                                                                                                                   \
+            hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kWaves, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,           \
+                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa); \
     } while (0)
     switch (G) {
         case 4:
@@ -1403,9 +1405,8 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
     const bool ride = T > 0 && !window_in_row_kernels();
     if (T > 0) {
         const WinArgs kw = ride ? WinArgs{kwin, knew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
-        if (prof) prof_mark(st, 0);
-        launch_key(st, k_bmp, static_cast<const unsigned char*>(k_nz), k_idx, k_nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores, kw);
-        if (prof) prof_mark(st, 1);
+        launch_key(st, k_bmp, static_cast<const unsigned char*>(k_nz), k_idx, k_nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores, kw,
+                   prof ? g_prof.ev[4 * g_prof.n] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr);
     }
     window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride ? nullptr : kwin, ride ? nullptr : knew, sc,
                                                                T, ld_scores, window_len, window_capacity, groups,
@@ -1421,9 +1422,9 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
         uint32_t* no_flags = nullptr;
         const WinArgs vw = ride ? WinArgs{vwin, vnew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
         if (ride) nwin_slabs = (window_capacity + kValueWinChunk - 1) / kValueWinChunk;
-        if (prof) prof_mark(st, 2);
-        launch_value(st, gv, v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores, vw);
-        if (prof) { prof_mark(st, 3); g_prof.n++; }
+        launch_value(st, gv, v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores, vw,
+                     prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr);
+        if (prof) g_prof.n++;
     }
     value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S + nwin_slabs, sc, ld_scores, T, ride ? nullptr : vwin, ride ? nullptr : vnew,
                                                     window_len, window_capacity, static_cast<h16*>(out), Batch_Size, groups,
