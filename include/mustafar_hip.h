@@ -113,6 +113,50 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
                               void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
                               const int32_t* window_len_extra);
 int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value_groups, int Split_K);
+
+/*
+ * Compressed cache with spare capacity (extension; SURVEY 8f rank 2: the reference re-copies bitmaps, offsets and every
+ * head's stream on each 256-token append, models/llama_mustafar_kernel.py:339-390).  Same four arrays as the reference
+ * format, but a head's bitmap / offset rows may be longer than the tokens in use, and NZ_offset may leave room behind
+ * every head's stream -- so an append writes only the new tokens:
+ *   bmp  [B', bmp_head_stride]   tiles [0, 2T) of a row in use        (bmp_head_stride >= 2T;     0 = exactly 2T)
+ *   idx  [B', idx_head_stride]   entries [0, 2T] of a row in use      (idx_head_stride >= 2T + 1; 0 = exactly 2T + 1)
+ */
+typedef struct mustafar_cache_view {
+    uint64_t* bmp;
+    void*     nz;
+    uint32_t* idx;
+    uint32_t* nz_offset;
+    int64_t   bmp_head_stride;
+    int64_t   idx_head_stride;
+} mustafar_cache_view;
+
+/* mustafar_decode_attention over two cache views (same semantics, same remaining arguments). */
+int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_cache, const mustafar_cache_view* v_cache,
+                                   const void* q, void* k_window, void* v_window, const void* k_new, const void* v_new,
+                                   int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
+                                   int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
+                                   const int32_t* window_len_extra);
+
+/*
+ * In-place append of t new (already pruned) tokens per head behind the `old_tokens` a view holds: the cache-append
+ * logic of the reference hook (models/llama_mustafar_kernel.py:339-390: shift the new offsets by the head's old total,
+ * splice bitmaps / offsets, concatenate the streams) as two device passes that touch only the new tokens.
+ *   pass 1  mustafar_cache_append_bitmap_{key,value}: bitmaps -> dst.bmp[h][2*old_tokens ...], offsets (continuing from
+ *           dst.idx[h][2*old_tokens]; that entry must hold the head's current total, 0 for an empty cache) ->
+ *           dst.idx[h][2*old_tokens + 1 ...]; head_total i64 [B'] = each head's NEW stream length in halfs.
+ *           The caller checks head_total against the room behind nz_offset[h] before pass 2 (one small device->host read).
+ *   pass 2  mustafar_cache_append_pack_{key,value}: the new tiles' non-zeros + padding -> dst.nz at 8*nz_offset[h] halfs.
+ * x fp16 [B', t, D], t % 64 == 0, old_tokens % 64 == 0.
+ */
+int mustafar_cache_append_bitmap_key(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
+                                     int old_tokens, int64_t* head_total);
+int mustafar_cache_append_bitmap_value(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
+                                       int old_tokens, int64_t* head_total);
+int mustafar_cache_append_pack_key(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
+                                   int old_tokens);
+int mustafar_cache_append_pack_value(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
+                                     int old_tokens);
 int mustafar_counter_add(void* stream, int32_t* counter, int delta);
 
 /*

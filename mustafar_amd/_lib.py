@@ -13,6 +13,15 @@ LIB_PATH = os.environ.get("MUSTAFAR_HIP_LIB") or os.path.join(_HERE, "lib", "lib
 
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 
+
+class CacheView(ctypes.Structure):
+    """`mustafar_cache_view` of include/mustafar_hip.h: the four arrays of the compressed format + the head strides."""
+    _fields_ = [("bmp", _vp), ("nz", _vp), ("idx", _vp), ("nz_offset", _vp),
+                ("bmp_head_stride", _i64), ("idx_head_stride", _i64)]
+
+
+_view_p = ctypes.POINTER(CacheView)
+
 # name -> (restype, argtypes); must list every symbol of include/mustafar_hip.h
 SIGNATURES = {
     "mustafar_abi_version": (_i32, []),
@@ -21,6 +30,12 @@ SIGNATURES = {
     "mustafar_value_pick_split_k": (_i32, [_i32] * 5),
     "mustafar_value_workspace_bytes": (_i64, [_i32] * 6),
     "mustafar_decode_attention": (_i32, [_vp] * 14 + [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_float, _vp]),
+    "mustafar_decode_attention_view": (_i32, [_vp, _view_p, _view_p] + [_vp] * 5 + [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
+                                              ctypes.c_float, _vp]),
+    "mustafar_cache_append_bitmap_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32, _vp]),
+    "mustafar_cache_append_bitmap_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32, _vp]),
+    "mustafar_cache_append_pack_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32]),
+    "mustafar_cache_append_pack_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32]),
     "mustafar_counter_add": (_i32, [_vp, _vp, _i32]),
     "mustafar_decode_workspace_bytes": (_i64, [_i32] * 4),
     "mustafar_set_fma_engine": (_i32, [_i32]),

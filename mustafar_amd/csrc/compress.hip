@@ -57,17 +57,25 @@ __global__ __launch_bounds__(kThreads) void prune_magnitude_kernel(const uint32_
 }
 
 // ------------------------------------------------------------------------------------------------ bitmaps
+// Destination rows of the passes: the reference's contiguous result tensors (bmp [B', 2t], accum [B', 2t + 1], stride =
+// row length, tile0 = 0) or rows of a cache view with spare capacity, written behind the tiles already in use
+// (in-place append: mustafar_cache_append_*).
+struct Rows {
+    int64_t bmp_stride;   // elements between the heads' bitmap rows
+    int64_t idx_stride;   // elements between the heads' offset rows
+    int64_t tile0;        // first tile of a row this call writes (2 * old_tokens)
+};
+
 // grid: x = token block (64 tokens), y = head.  Writes the 128 bitmaps of the block and the raw padded
 // counts (half2 units) into accum[h][tile + 1]; the scan kernel turns them into the exclusive prefix.
 
 // V: tile (tb, half, r) = channels half*64..+63 of token tb*64+r (compression.py:87-97); lane = channel.
-__global__ __launch_bounds__(kThreads) void bitmap_value_kernel(const uint16_t* __restrict__ x, int t,
-                                                                int64_t* __restrict__ bmp, int32_t* __restrict__ accum)
+__global__ __launch_bounds__(kThreads) void bitmap_value_kernel(const uint16_t* __restrict__ x, int t, int64_t* __restrict__ bmp,
+                                                                int32_t* __restrict__ accum, Rows rows)
 {
     __shared__ uint64_t s_bmp[kD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tb = blockIdx.x, h = blockIdx.y;
-    const int64_t tiles = (int64_t)t * kD / 64;
     const uint16_t* xb = x + ((int64_t)h * t + (int64_t)tb * 64) * kD;
     for (int r = wave; r < 64; r += kWaves) {
         const uint16_t a = xb[r * kD + lane], b = xb[r * kD + 64 + lane];
@@ -82,8 +90,8 @@ __global__ __launch_bounds__(kThreads) void bitmap_value_kernel(const uint16_t* 
     if (threadIdx.x < kD) {
         const uint64_t m = s_bmp[threadIdx.x];
         const int64_t tile = (int64_t)tb * kD + threadIdx.x;
-        bmp[h * tiles + tile] = (int64_t)m;
-        accum[h * (tiles + 1) + tile + 1] = ((__popcll(m) + 7) & ~7) >> 1;   // compression.py:46-48
+        bmp[h * rows.bmp_stride + rows.tile0 + tile] = (int64_t)m;
+        accum[h * rows.idx_stride + rows.tile0 + tile + 1] = ((__popcll(m) + 7) & ~7) >> 1;   // compression.py:46-48
     }
 }
 
@@ -109,14 +117,13 @@ __device__ __forceinline__ uint16_t block_elem(const uint32_t* s_blk, int token,
     return (uint16_t)((d & 1) ? (w >> 16) : (w & 0xffffu));
 }
 
-__global__ __launch_bounds__(kThreads) void bitmap_key_kernel(const uint16_t* __restrict__ x, int t,
-                                                              int64_t* __restrict__ bmp, int32_t* __restrict__ accum)
+__global__ __launch_bounds__(kThreads) void bitmap_key_kernel(const uint16_t* __restrict__ x, int t, int64_t* __restrict__ bmp,
+                                                                int32_t* __restrict__ accum, Rows rows)
 {
     __shared__ uint32_t s_blk[64 * kRowWords];
     __shared__ uint64_t s_bmp[kD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tb = blockIdx.x, h = blockIdx.y;
-    const int64_t tiles = (int64_t)t * kD / 64;
     load_block_transposable(s_blk, x + ((int64_t)h * t + (int64_t)tb * 64) * kD);
     __syncthreads();
     for (int d = wave; d < kD; d += kWaves) {
@@ -127,21 +134,22 @@ __global__ __launch_bounds__(kThreads) void bitmap_key_kernel(const uint16_t* __
     if (threadIdx.x < kD) {
         const uint64_t m = s_bmp[threadIdx.x];
         const int64_t tile = (int64_t)tb * kD + threadIdx.x;
-        bmp[h * tiles + tile] = (int64_t)m;
-        accum[h * (tiles + 1) + tile + 1] = ((__popcll(m) + 7) & ~7) >> 1;
+        bmp[h * rows.bmp_stride + rows.tile0 + tile] = (int64_t)m;
+        accum[h * rows.idx_stride + rows.tile0 + tile + 1] = ((__popcll(m) + 7) & ~7) >> 1;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ scan
 // accum[h][0] = 0, accum[h][i+1] = sum of raw counts [0..i]  (torch.cumsum + cat, compression.py:294-298).
-// One workgroup per head walks the tiles 256 at a time with a running carry.
+// One workgroup per head walks the tiles 256 at a time with a running carry.  Append mode (rows.tile0 > 0): the walk
+// starts at the head's entry tile0, which already holds the total of the tiles in use (model :352-360).
 __global__ __launch_bounds__(kThreads) void scan_counts_kernel(int32_t* __restrict__ accum, int64_t tiles,
-                                                               int64_t* __restrict__ totals)
+                                                               int64_t* __restrict__ totals, Rows rows)
 {
     __shared__ int32_t s_wave[kWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t* a = accum + (int64_t)blockIdx.x * (tiles + 1);
-    int32_t carry = 0;
+    int32_t* a = accum + (int64_t)blockIdx.x * rows.idx_stride + rows.tile0;
+    int32_t carry = rows.tile0 ? a[0] : 0;
     for (int64_t base = 0; base < tiles; base += kThreads) {
         const int64_t i = base + threadIdx.x;
         int32_t v = (i < tiles) ? a[i + 1] : 0;
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void scan_counts_kernel(int32_t* __restri
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        a[0] = 0;
+        if (rows.tile0 == 0) a[0] = 0;
         totals[blockIdx.x] = 2 * (int64_t)carry;   // halfs in this head's stream (compression.py:302)
     }
 }
@@ -192,17 +200,23 @@ __device__ __forceinline__ void pack_tile(uint16_t* __restrict__ dst, uint16_t v
     if (lane >= nnz && lane < padded) dst[lane] = 0;
 }
 
+// Start of head h's stream in halfs: head_off[h] (fresh result tensor) or 8 * nz_offset[h] (cache view).
+__device__ __forceinline__ int64_t head_base(const int64_t* __restrict__ head_off, const uint32_t* __restrict__ nz_offset, int h)
+{
+    return head_off ? head_off[h] : 8 * (int64_t)nz_offset[h];
+}
+
 __global__ __launch_bounds__(kThreads) void pack_value_kernel(const uint16_t* __restrict__ x, int t,
                                                               const int32_t* __restrict__ accum,
                                                               const int64_t* __restrict__ head_off,
-                                                              uint16_t* __restrict__ nz)
+                                                              const uint32_t* __restrict__ nz_offset,
+                                                              uint16_t* __restrict__ nz, Rows rows)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tb = blockIdx.x, h = blockIdx.y;
-    const int64_t tiles = (int64_t)t * kD / 64;
     const uint16_t* xb = x + ((int64_t)h * t + (int64_t)tb * 64) * kD;
-    const int32_t* acc = accum + (int64_t)h * (tiles + 1) + (int64_t)tb * kD;
-    uint16_t* nz_h = nz + head_off[h];
+    const int32_t* acc = accum + (int64_t)h * rows.idx_stride + rows.tile0 + (int64_t)tb * kD;
+    uint16_t* nz_h = nz + head_base(head_off, nz_offset, h);
     for (int r = wave; r < 64; r += kWaves) {
         pack_tile(nz_h + 2 * (int64_t)acc[r], xb[r * kD + lane], lane);
         pack_tile(nz_h + 2 * (int64_t)acc[64 + r], xb[r * kD + 64 + lane], lane);
@@ -212,47 +226,59 @@ __global__ __launch_bounds__(kThreads) void pack_value_kernel(const uint16_t* __
 __global__ __launch_bounds__(kThreads) void pack_key_kernel(const uint16_t* __restrict__ x, int t,
                                                             const int32_t* __restrict__ accum,
                                                             const int64_t* __restrict__ head_off,
-                                                            uint16_t* __restrict__ nz)
+                                                            const uint32_t* __restrict__ nz_offset,
+                                                            uint16_t* __restrict__ nz, Rows rows)
 {
     __shared__ uint32_t s_blk[64 * kRowWords];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tb = blockIdx.x, h = blockIdx.y;
-    const int64_t tiles = (int64_t)t * kD / 64;
     load_block_transposable(s_blk, x + ((int64_t)h * t + (int64_t)tb * 64) * kD);
     __syncthreads();
-    const int32_t* acc = accum + (int64_t)h * (tiles + 1) + (int64_t)tb * kD;
-    uint16_t* nz_h = nz + head_off[h];
+    const int32_t* acc = accum + (int64_t)h * rows.idx_stride + rows.tile0 + (int64_t)tb * kD;
+    uint16_t* nz_h = nz + head_base(head_off, nz_offset, h);
     for (int d = wave; d < kD; d += kWaves)
         pack_tile(nz_h + 2 * (int64_t)acc[d], block_elem(s_blk, lane, d), lane);
 }
 
 int bitmap_common(bool key, void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
-                  int64_t* head_off)
+                  int64_t* totals, Rows rows, bool exclusive_prefix)
 {
-    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || !head_off) return MUSTAFAR_EINVAL;
+    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || !totals) return MUSTAFAR_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(t / 64, Bp);
     const int64_t tiles = (int64_t)t * kD / 64;
     auto xs = static_cast<const uint16_t*>(x);
-    if (key) bitmap_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum);
-    else     bitmap_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum);
-    scan_counts_kernel<<<Bp, kThreads, 0, st>>>(accum, tiles, head_off);
-    head_offsets_kernel<<<1, 64, 0, st>>>(head_off, Bp);
+    if (key) bitmap_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, rows);
+    else     bitmap_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, rows);
+    scan_counts_kernel<<<Bp, kThreads, 0, st>>>(accum, tiles, totals, rows);
+    if (exclusive_prefix) head_offsets_kernel<<<1, 64, 0, st>>>(totals, Bp);
     return (int)hipGetLastError();
 }
 
 int pack_common(bool key, void* stream, const void* x, int Bp, int t, int D, const int32_t* accum,
-                const int64_t* head_off, void* nz_flat)
+                const int64_t* head_off, const uint32_t* nz_offset, void* nz_flat, Rows rows)
 {
-    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !accum || !head_off) return MUSTAFAR_EINVAL;
+    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !accum || (!head_off && !nz_offset)) return MUSTAFAR_EINVAL;
     if (!nz_flat) return 0;   // nothing to write: every tile of every head is empty
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(t / 64, Bp);
     auto xs = static_cast<const uint16_t*>(x);
     auto nz = static_cast<uint16_t*>(nz_flat);
-    if (key) pack_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, accum, head_off, nz);
-    else     pack_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, accum, head_off, nz);
+    if (key) pack_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, accum, head_off, nz_offset, nz, rows);
+    else     pack_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, accum, head_off, nz_offset, nz, rows);
     return (int)hipGetLastError();
+}
+
+inline Rows fresh_rows(int t) { const int64_t tiles = (int64_t)t * kD / 64; return Rows{tiles, tiles + 1, 0}; }
+
+// Rows of a cache view behind `old_tokens`; false if the view cannot take t more tokens.
+inline bool view_rows(const mustafar_cache_view* v, int old_tokens, int t, Rows& rows)
+{
+    if (!v || !v->bmp || !v->idx || !v->nz_offset || old_tokens < 0 || (old_tokens & 63)) return false;
+    const int64_t tiles = (int64_t)(old_tokens + t) * kD / 64;
+    rows = Rows{v->bmp_head_stride ? v->bmp_head_stride : tiles, v->idx_head_stride ? v->idx_head_stride : tiles + 1,
+                (int64_t)old_tokens * kD / 64};
+    return rows.bmp_stride >= tiles && rows.idx_stride >= tiles + 1;
 }
 
 }  // namespace
@@ -272,18 +298,53 @@ int mustafar_prune_magnitude(void* stream, const void* x, void* out, int64_t n_r
 
 int mustafar_compress_bitmap_key(void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
                                  int64_t* head_off)
-{ return bitmap_common(true, stream, x, Bp, t, D, bmp, accum, head_off); }
+{ return bitmap_common(true, stream, x, Bp, t, D, bmp, accum, head_off, fresh_rows(t), true); }
 
 int mustafar_compress_bitmap_value(void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
                                    int64_t* head_off)
-{ return bitmap_common(false, stream, x, Bp, t, D, bmp, accum, head_off); }
+{ return bitmap_common(false, stream, x, Bp, t, D, bmp, accum, head_off, fresh_rows(t), true); }
 
 int mustafar_compress_pack_key(void* stream, const void* x, int Bp, int t, int D, const int64_t* /*bmp*/,
                                const int32_t* accum, const int64_t* head_off, void* nz_flat)
-{ return pack_common(true, stream, x, Bp, t, D, accum, head_off, nz_flat); }
+{ return pack_common(true, stream, x, Bp, t, D, accum, head_off, nullptr, nz_flat, fresh_rows(t)); }
 
 int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int D, const int64_t* /*bmp*/,
                                  const int32_t* accum, const int64_t* head_off, void* nz_flat)
-{ return pack_common(false, stream, x, Bp, t, D, accum, head_off, nz_flat); }
+{ return pack_common(false, stream, x, Bp, t, D, accum, head_off, nullptr, nz_flat, fresh_rows(t)); }
+
+// ---- in-place append into a cache view (model :339-390 without the re-copies) ----------------------------------------
+int mustafar_cache_append_bitmap_key(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
+                                     int old_tokens, int64_t* head_total)
+{
+    Rows rows;
+    if (!view_rows(dst, old_tokens, t, rows)) return MUSTAFAR_EINVAL;
+    return bitmap_common(true, stream, x, Bp, t, D, reinterpret_cast<int64_t*>(dst->bmp), reinterpret_cast<int32_t*>(dst->idx),
+                         head_total, rows, false);
+}
+
+int mustafar_cache_append_bitmap_value(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
+                                       int old_tokens, int64_t* head_total)
+{
+    Rows rows;
+    if (!view_rows(dst, old_tokens, t, rows)) return MUSTAFAR_EINVAL;
+    return bitmap_common(false, stream, x, Bp, t, D, reinterpret_cast<int64_t*>(dst->bmp), reinterpret_cast<int32_t*>(dst->idx),
+                         head_total, rows, false);
+}
+
+int mustafar_cache_append_pack_key(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
+                                   int old_tokens)
+{
+    Rows rows;
+    if (!view_rows(dst, old_tokens, t, rows) || !dst->nz) return MUSTAFAR_EINVAL;
+    return pack_common(true, stream, x, Bp, t, D, reinterpret_cast<const int32_t*>(dst->idx), nullptr, dst->nz_offset, dst->nz, rows);
+}
+
+int mustafar_cache_append_pack_value(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
+                                     int old_tokens)
+{
+    Rows rows;
+    if (!view_rows(dst, old_tokens, t, rows) || !dst->nz) return MUSTAFAR_EINVAL;
+    return pack_common(false, stream, x, Bp, t, D, reinterpret_cast<const int32_t*>(dst->idx), nullptr, dst->nz_offset, dst->nz, rows);
+}
 
 }  // extern "C"

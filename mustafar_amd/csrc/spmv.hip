@@ -662,8 +662,9 @@ template <int G, bool MF, int SPLIT>
 __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int N, int groups,
-    int ldc, WinArgs wa)   // ldc: row stride of `out` in halfs (T for the reference layout)
-{
+    int ldc, WinArgs wa, int64_t bmp_stride, int64_t idx_stride)
+{   // ldc: row stride of `out` in halfs (T for the reference layout); bmp_stride / idx_stride: elements between the heads'
+    // rows of `bmp` / `idx` (0 = the reference's contiguous layout, 2T and 2T + 1; larger for an arena with spare capacity)
     constexpr int kTabBytes = (MF && G == 4) ? 4 * kD * 2 : 0;   // MFMA engine: q rows of the 4 heads
     __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
     MUSTAFAR_TRACE_BEGIN(1);
@@ -687,8 +688,8 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     const int part = wave % SPLIT;   // which half of the channels this wave covers (SPLIT = 2)
     const int64_t tiles = (int64_t)ntb * kTilesPerTb;
 
-    const uint64_t* bmp_t = bmp + (int64_t)kvh * tiles + (int64_t)tb * kTilesPerTb;
-    const uint32_t* idx_t = idx + (int64_t)kvh * (tiles + 1) + (int64_t)tb * kTilesPerTb;
+    const uint64_t* bmp_t = bmp + (int64_t)kvh * (bmp_stride ? bmp_stride : tiles) + (int64_t)tb * kTilesPerTb;
+    const uint32_t* idx_t = idx + (int64_t)kvh * (idx_stride ? idx_stride : tiles + 1) + (int64_t)tb * kTilesPerTb;
     const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
     const uint32_t chead = (uint32_t)N * (kD / 2);
 
@@ -858,8 +859,9 @@ template <int G, bool MF, int NW, int SPLIT>
 __global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
-    uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb, WinArgs wa)
-{   // ldb: row stride of `p` in halfs (T for the reference layout; must be even, % 8 == 0 for the MFMA engine)
+    uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb, WinArgs wa,
+    int64_t bmp_stride, int64_t idx_stride)
+{   // bmp_stride / idx_stride: as in key_spmv_kernel;  ldb: row stride of `p` in halfs (T for the reference layout; must be even, % 8 == 0 for the MFMA engine)
     constexpr int kTabBytes = (MF && G == 4) ? NW * 512 : 0;
     constexpr int kStride = NW / SPLIT;   // token blocks in flight per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char smem[NW * kStageBytes + kTabBytes];
@@ -884,8 +886,8 @@ __global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
     const int tb_end = min(ntb, tb0 + tb_per_wg);
     const int64_t tiles = (int64_t)ntb * kTilesPerTb;
 
-    const uint64_t* bmp_h = bmp + (int64_t)kvh * tiles;
-    const uint32_t* idx_h = idx + (int64_t)kvh * (tiles + 1);
+    const uint64_t* bmp_h = bmp + (int64_t)kvh * (bmp_stride ? bmp_stride : tiles);
+    const uint32_t* idx_h = idx + (int64_t)kvh * (idx_stride ? idx_stride : tiles + 1);
     const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
     float* red = reinterpret_cast<float*>(smem);   // [NW][2*G][64], overlays the stage windows
     float* ws_slab = ws + (int64_t)blockIdx.x * BH * N * kD;
@@ -1209,7 +1211,8 @@ struct Profile {
 // One place that picks the key kernel instantiation: G heads per pass, FMA engine, waves per token block.
 void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx, const uint32_t* nz_off,
                 const h16* q, h16* out, int T, int N, int groups, int Batch_Size, int ldc, WinArgs wa = WinArgs{},
-                hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)   // ev0/ev1: the kernel's own start / stop timestamps
+                hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,   // ev0/ev1: the kernel's own start / stop timestamps
+                int64_t bmp_stride = 0, int64_t idx_stride = 0)
 {
     const int G = pick_g(groups);
     const int gy = (Batch_Size / groups) * (groups / G);
@@ -1225,9 +1228,9 @@ void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, co
 #define MUSTAFAR_LK(GG, MFF)                                                                                                   \
     do {                                                                                                                       \
         if (split == 2) hipExtLaunchKernelGGL((key_spmv_kernel<GG, MFF, 2>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,         \
-                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa);                           \
+                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa, bmp_stride, idx_stride);   \
         else            hipExtLaunchKernelGGL((key_spmv_kernel<GG, MFF, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,         \
-                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa);                           \
+                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa, bmp_stride, idx_stride);   \
     } while (0)
     switch (G) {
         case 4:
@@ -1259,7 +1262,7 @@ inline int value_tb_stride() { return value_split() == 2 ? kValueWaves / 2 : kWa
 void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx,
                   const uint32_t* nz_off, const h16* p, h16* out, float* ws, uint32_t* flags, int T, int N, int groups,
                   int Batch_Size, int tb_per_wg, int direct, int ldb, WinArgs wa = WinArgs{}, hipEvent_t ev0 = nullptr,
-                  hipEvent_t ev1 = nullptr)
+                  hipEvent_t ev1 = nullptr, int64_t bmp_stride = 0, int64_t idx_stride = 0)
 {
     const int G = pick_g(groups);
     if (wa.win) {   // window workgroups first; their partial slabs follow the grid.x token-chunk slabs
@@ -1271,10 +1274,10 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
     do {                                                                                                                       \
         if (value_split() == 2)                                                                                                \
             hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kValueWaves, 2>), grid, dim3(kValueWaves * 64), 0, st, ev0, ev1, 0, \
-                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa); \
+                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride); \
         else                                                                                                                   \
             hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kWaves, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,           \
-                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa); \
+                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride); \
     } while (0)
     switch (G) {
         case 4:
@@ -1375,12 +1378,13 @@ int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value
     return (int64_t)((Split_K < 1 ? 1 : Split_K) + kMaxWindow / kValueWinChunk) * Batch_Size * kD * (int64_t)sizeof(float);
 }
 
-int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k_nz, const uint32_t* k_idx,
-                              const uint32_t* k_nz_offset, const uint64_t* v_bmp, const void* v_nz, const uint32_t* v_idx,
-                              const uint32_t* v_nz_offset, const void* q, void* k_window, void* v_window, const void* k_new,
-                              const void* v_new, int window_len, int window_capacity, void* scores, int ld_scores, void* out,
-                              void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
-                              const int32_t* window_len_extra)
+}  // extern "C"
+
+namespace {
+int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar_cache_view& vc, const void* q, void* k_window,
+                     void* v_window, const void* k_new, const void* v_new, int window_len, int window_capacity, void* scores,
+                     int ld_scores, void* out, void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups,
+                     float sqrt_d, const int32_t* window_len_extra)
 {
     const int groups = num_key_value_groups;
     if (T < 0 || (T & 63) || groups < 1 || Batch_Size < 1 || Batch_Size % groups || window_len < 1 ||
@@ -1388,7 +1392,11 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
         ld_scores < T + (window_len_extra ? window_capacity : window_len) || (ld_scores & 7) || Split_K < 1 || !(sqrt_d > 0.f))
         return MUSTAFAR_EINVAL;
     if (!q || !k_window || !v_window || !scores || !out || !workspace) return MUSTAFAR_EINVAL;
-    if (T > 0 && (!k_bmp || !k_nz || !k_idx || !k_nz_offset || !v_bmp || !v_nz || !v_idx || !v_nz_offset)) return MUSTAFAR_EINVAL;
+    if (T > 0 && (!kc.bmp || !kc.nz || !kc.idx || !kc.nz_offset || !vc.bmp || !vc.nz || !vc.idx || !vc.nz_offset)) return MUSTAFAR_EINVAL;
+    const int64_t tiles = (int64_t)T * 2;
+    if (T > 0 && ((kc.bmp_head_stride && kc.bmp_head_stride < tiles) || (kc.idx_head_stride && kc.idx_head_stride < tiles + 1) ||
+                  (vc.bmp_head_stride && vc.bmp_head_stride < tiles) || (vc.idx_head_stride && vc.idx_head_stride < tiles + 1)))
+        return MUSTAFAR_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto qh = static_cast<const h16*>(q);
     auto sc = static_cast<h16*>(scores);
@@ -1405,8 +1413,9 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
     const bool ride = T > 0 && !window_in_row_kernels();
     if (T > 0) {
         const WinArgs kw = ride ? WinArgs{kwin, knew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
-        launch_key(st, k_bmp, static_cast<const unsigned char*>(k_nz), k_idx, k_nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores, kw,
-                   prof ? g_prof.ev[4 * g_prof.n] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr);
+        launch_key(st, kc.bmp, static_cast<const unsigned char*>(kc.nz), kc.idx, kc.nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores, kw,
+                   prof ? g_prof.ev[4 * g_prof.n] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr, kc.bmp_head_stride,
+                   kc.idx_head_stride);
     }
     window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride ? nullptr : kwin, ride ? nullptr : knew, sc,
                                                                T, ld_scores, window_len, window_capacity, groups,
@@ -1417,13 +1426,14 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
         const int tb_per_wg = (ntb + Split_K - 1) / Split_K;
         S = (ntb + tb_per_wg - 1) / tb_per_wg;
         const dim3 gv(S, gy);
-        auto nz = static_cast<const unsigned char*>(v_nz);
+        auto nz = static_cast<const unsigned char*>(vc.nz);
         h16* no_out = nullptr;
         uint32_t* no_flags = nullptr;
         const WinArgs vw = ride ? WinArgs{vwin, vnew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
         if (ride) nwin_slabs = (window_capacity + kValueWinChunk - 1) / kValueWinChunk;
-        launch_value(st, gv, v_bmp, nz, v_idx, v_nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores, vw,
-                     prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr);
+        launch_value(st, gv, vc.bmp, nz, vc.idx, vc.nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores, vw,
+                     prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, vc.bmp_head_stride,
+                     vc.idx_head_stride);
         if (prof) g_prof.n++;
     }
     value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S + nwin_slabs, sc, ld_scores, T, ride ? nullptr : vwin, ride ? nullptr : vnew,
@@ -1431,7 +1441,37 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
                                                     window_len_extra);
     return (int)hipGetLastError();
 }
+}  // namespace
 
+extern "C" {
+
+int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k_nz, const uint32_t* k_idx,
+                              const uint32_t* k_nz_offset, const uint64_t* v_bmp, const void* v_nz, const uint32_t* v_idx,
+                              const uint32_t* v_nz_offset, const void* q, void* k_window, void* v_window, const void* k_new,
+                              const void* v_new, int window_len, int window_capacity, void* scores, int ld_scores, void* out,
+                              void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
+                              const int32_t* window_len_extra)
+{
+    const mustafar_cache_view kc{const_cast<uint64_t*>(k_bmp), const_cast<void*>(k_nz), const_cast<uint32_t*>(k_idx),
+                                 const_cast<uint32_t*>(k_nz_offset), 0, 0};
+    const mustafar_cache_view vc{const_cast<uint64_t*>(v_bmp), const_cast<void*>(v_nz), const_cast<uint32_t*>(v_idx),
+                                 const_cast<uint32_t*>(v_nz_offset), 0, 0};
+    return decode_attention(stream, kc, vc, q, k_window, v_window, k_new, v_new, window_len, window_capacity, scores, ld_scores, out,
+                            workspace, Split_K, T, Batch_Size, num_key_value_groups, sqrt_d, window_len_extra);
+}
+
+int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_cache, const mustafar_cache_view* v_cache,
+                                   const void* q, void* k_window, void* v_window, const void* k_new, const void* v_new,
+                                   int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
+                                   int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
+                                   const int32_t* window_len_extra)
+{
+    const mustafar_cache_view none{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (T > 0 && (!k_cache || !v_cache)) return MUSTAFAR_EINVAL;
+    return decode_attention(stream, k_cache ? *k_cache : none, v_cache ? *v_cache : none, q, k_window, v_window, k_new, v_new,
+                            window_len, window_capacity, scores, ld_scores, out, workspace, Split_K, T, Batch_Size,
+                            num_key_value_groups, sqrt_d, window_len_extra);
+}
 
 int mustafar_profile_begin(int max_records)
 {

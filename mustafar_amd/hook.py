@@ -29,6 +29,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, compression, mustafar_package
+from .cache import CompressedArena
 
 
 @dataclass
@@ -41,6 +42,7 @@ class MustafarConfig:
     residual_length: int = 32     # mem_spd_test.py:9, :22
     group_size: int = 32          # carried by the reference config, unused on the kernel path
     api: str = "native"           # "reference" | "native" | "fused"
+    arena: bool = False           # api="fused": keep the compressed cache in CompressedArena objects (in-place append)
 
 
 def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:
@@ -166,9 +168,13 @@ class MustafarAttention:
         if compressed_length != 0:
             k_pruned = self.dh_prune_key(key_states[:, :, :compressed_length, :])                     # :419
             v_pruned = self.dh_prune_value(value_states[:, :, :compressed_length, :])                 # :420
-            k_compressed = _compress(k_pruned.reshape(total_batch_kv, -1, D), "key")                  # :422-426
+            if self.cfg.arena and self.cfg.api == "fused":   # straight into appendable storage
+                k_compressed = CompressedArena.from_pruned(k_pruned.reshape(total_batch_kv, -1, D), "key")
+                v_compressed = CompressedArena.from_pruned(v_pruned.reshape(total_batch_kv, -1, D), "value")
+            else:
+                k_compressed = _compress(k_pruned.reshape(total_batch_kv, -1, D), "key")              # :422-426
+                v_compressed = _compress(v_pruned.reshape(total_batch_kv, -1, D), "value")            # :430-434
             k_local_window = key_states[:, :, compressed_length:, :].clone().contiguous()             # :427
-            v_compressed = _compress(v_pruned.reshape(total_batch_kv, -1, D), "value")                # :430-434
             v_local_window = value_states[:, :, compressed_length:, :].clone().contiguous()           # :435
         else:
             k_compressed, k_local_window, v_compressed, v_local_window = None, key_states, None, value_states
@@ -185,8 +191,11 @@ class MustafarAttention:
     def to_fused(self, past):
         """Wrap the two local windows of a reference-layout `past` into appendable buffers."""
         k_c, k_w, v_c, v_w, C, L = past
+        if self.cfg.arena and C and not isinstance(k_c, CompressedArena):
+            k_c = CompressedArena.from_reference(k_c, "key", C)
+            v_c = CompressedArena.from_reference(v_c, "value", C)
         if isinstance(k_w, Window):
-            return past
+            return (k_c, k_w, v_c, v_w, C, L)
         cap = self.cfg.residual_length + 256 + 64
         return (k_c, Window(k_w, cap), v_c, Window(v_w, cap), C, L)
 
@@ -235,26 +244,38 @@ class MustafarAttention:
         if k_w.cap != v_w.cap:
             raise RuntimeError("key/value windows must have the same capacity")
         p = lambda t: t.data_ptr() if t is not None else None
-        with torch.cuda.device(dev):
-            err = L.mustafar_decode_attention(
-                torch.cuda.current_stream(dev).cuda_stream,
-                p(k_c[0]) if C else None, p(k_c[2].flat) if C else None, p(k_c[1]) if C else None, p(k_c[3]) if C else None,
-                p(v_c[0]) if C else None, p(v_c[2].flat) if C else None, p(v_c[1]) if C else None, p(v_c[3]) if C else None,
-                q.data_ptr(), k_w.buf.data_ptr(), v_w.buf.data_ptr(), kn.data_ptr(), vn.data_ptr(), w_len, k_w.cap,
+        use_arena = isinstance(k_c, CompressedArena)
+        tail = (q.data_ptr(), k_w.buf.data_ptr(), v_w.buf.data_ptr(), kn.data_ptr(), vn.data_ptr(), w_len, k_w.cap,
                 scores.data_ptr(), ld, out.data_ptr(), ws.data_ptr(), split, C, BH, groups, math.sqrt(D),
                 step_counter.data_ptr() if step_counter is not None else None)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            if use_arena:
+                err = L.mustafar_decode_attention_view(st, k_c.view_ptr(), v_c.view_ptr(), *tail)
+            else:
+                err = L.mustafar_decode_attention(
+                    st, p(k_c[0]) if C else None, p(k_c[2].flat) if C else None, p(k_c[1]) if C else None, p(k_c[3]) if C else None,
+                    p(v_c[0]) if C else None, p(v_c[2].flat) if C else None, p(v_c[1]) if C else None, p(v_c[3]) if C else None, *tail)
         _lib.check(err, "mustafar_decode_attention")
         if step_counter is not None:
             return out, (k_c, k_w, v_c, v_w, C, kv_seq_len - 1)   # lengths advance with the device counter
         k_w.len = v_w.len = w_len
         if (kv_seq_len - cfg.residual_length - C) % 256 == 0 and w_len >= 256:                          # :324
-            k_new = _compress(self.dh_prune_key(k_w.buf[:, :, :256, :]).reshape(Bkv, -1, D), "key")     # :325-340
-            v_new = _compress(self.dh_prune_value(v_w.buf[:, :, :256, :]).reshape(Bkv, -1, D), "value")
-            if C == 0:
-                k_c, v_c = k_new, v_new
+            k_blk = self.dh_prune_key(k_w.buf[:, :, :256, :]).reshape(Bkv, -1, D)                       # :325
+            v_blk = self.dh_prune_value(v_w.buf[:, :, :256, :]).reshape(Bkv, -1, D)                     # :326
+            if use_arena or (cfg.arena and C == 0):
+                if C == 0:
+                    k_c, v_c = CompressedArena.from_pruned(k_blk, "key"), CompressedArena.from_pruned(v_blk, "value")
+                else:
+                    k_c.append(k_blk)                                                                   # :339-390, in place
+                    v_c.append(v_blk)
             else:
-                k_c = append_compressed(k_c, k_new, Bkv, C, 256, D)
-                v_c = append_compressed(v_c, v_new, Bkv, C, 256, D)
+                k_new, v_new = _compress(k_blk, "key"), _compress(v_blk, "value")                       # :328-337
+                if C == 0:
+                    k_c, v_c = k_new, v_new
+                else:
+                    k_c = append_compressed(k_c, k_new, Bkv, C, 256, D)
+                    v_c = append_compressed(v_c, v_new, Bkv, C, 256, D)
             k_w.drop_front(256)                                                                         # :392-393
             v_w.drop_front(256)
             C += 256
@@ -268,6 +289,8 @@ class MustafarAttention:
             return self.decode_fused(query_states, key_states, value_states, past)
         if isinstance(past[1], Window):   # a fused cache handed to the unfused path
             past = (past[0], past[1].view(), past[2], past[3].view(), past[4], past[5])
+        if isinstance(past[0], CompressedArena):
+            past = (past[0].to_reference(), past[1], past[2].to_reference(), past[3], past[4], past[5])
         bsz, _, q_len, D = query_states.shape
         total_batch_size = bsz * self.num_heads
         total_batch_kv = bsz * self.num_key_value_heads

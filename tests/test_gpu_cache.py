@@ -1,0 +1,120 @@
+"""GPU: the device-resident cache container (mustafar_amd/cache.py) -- in-place append of the reference's cache-append
+logic (models/llama_mustafar_kernel.py:339-390).  Bars: bitmaps, offsets and streams after appends are BIT-EXACT equal to
+the reference-format compression of the concatenated tokens (oracle) and to the hook's tensor-op append; decode through a
+cache view gives the same bits as decode through the contiguous layout."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pruned(heads, t, s, seed):
+    from mustafar_amd import compression
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn((heads, t, 128), device=DEV, generator=g).half()
+    return compression.prune_magnitude(x, s)
+
+
+def _assert_same_as_oracle(arena, x_all, which):
+    conv = orc.convert_key_batched if which == "key" else orc.convert_value_batched
+    bmp, idx, nzs = conv(x_all.cpu().numpy())
+    got = arena.to_reference()
+    assert np.array_equal(got[0].cpu().numpy(), bmp)
+    assert np.array_equal(got[1].cpu().numpy(), idx)
+    assert len(got[2]) == len(nzs)
+    for a, b in zip(got[2], nzs):
+        assert np.array_equal(a.cpu().numpy().view(np.uint16), np.asarray(b).view(np.uint16))
+    assert np.array_equal(got[3].cpu().numpy(), orc.nz_offset_from_idx(idx))
+
+
+@pytest.mark.parametrize("which", ["key", "value"])
+@pytest.mark.parametrize("heads,s", [(3, 0.7), (8, 0.5)])
+def test_appends_match_compression_of_the_concatenation(which, heads, s):
+    from mustafar_amd.cache import CompressedArena
+    x1, x2, x3 = _pruned(heads, 512, s, 1), _pruned(heads, 256, s, 2), _pruned(heads, 64, s, 3)
+    arena = CompressedArena.from_pruned(x1, which)
+    _assert_same_as_oracle(arena, x1, which)
+    arena.append(x2)
+    arena.append(x3)
+    assert arena.tokens == 832
+    _assert_same_as_oracle(arena, torch.cat([x1, x2, x3], 1), which)
+
+
+@pytest.mark.parametrize("which", ["key", "value"])
+def test_growth_of_rows_and_stream_regions(which):
+    """Capacities far too small on purpose: token rows and stream regions are re-housed, contents stay exact."""
+    from mustafar_amd.cache import CompressedArena
+    heads = 4
+    arena = CompressedArena(heads, which, torch.device(DEV), cap_tokens=256, nz_cap=4096)
+    parts = [_pruned(heads, 256, 0.5, 10 + i) for i in range(4)]
+    for i, x in enumerate(parts):
+        arena.append(x)
+        _assert_same_as_oracle(arena, torch.cat(parts[: i + 1], 1), which)
+    assert arena.cap_tokens >= 1024 and arena.nz_cap >= int(arena.used.max())
+    # dense input (nothing pruned, every tile full) and an all-zero block in the same cache
+    dense = torch.randn((heads, 64, 128), device=DEV).half()
+    dense[dense == 0] = 1
+    arena.append(dense)
+    arena.append(torch.zeros((heads, 64, 128), device=DEV, dtype=torch.float16))
+    _assert_same_as_oracle(arena, torch.cat(parts + [dense, torch.zeros_like(dense)], 1), which)
+
+
+def test_from_reference_round_trip_and_hook_append_equivalence():
+    """Arena append == the hook's tensor-op append (append_compressed, model :339-390) on the reference layout."""
+    from mustafar_amd.cache import CompressedArena
+    from mustafar_amd.hook import _compress, append_compressed
+    heads = 6
+    x1, x2 = _pruned(heads, 512, 0.7, 5), _pruned(heads, 256, 0.7, 6)
+    ref = append_compressed(_compress(x1, "value"), _compress(x2, "value"), heads, 512, 256, 128)
+    arena = CompressedArena.from_reference(_compress(x1, "value"), "value", 512)
+    arena.append(x2)
+    got = arena.to_reference()
+    assert torch.equal(got[0].flatten(), ref[0].flatten()) and torch.equal(got[1].flatten(), ref[1].flatten())
+    assert torch.equal(got[3], ref[3])
+    for a, b in zip(got[2], ref[2]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4)])
+def test_decode_through_arena_is_bit_identical(hq, hkv):
+    """Same prompt, same steps, across a 256-token trigger: arena cache vs contiguous cache, fused entry point."""
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    from mustafar_amd.cache import CompressedArena
+    torch.manual_seed(3)
+    bsz, D, L0 = 2, 128, 300
+    K = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    V = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    attns = [MustafarAttention(MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, api="fused", arena=a))
+             for a in (False, True)]
+    pasts = [a.to_fused(a.build_cache(K.clone(), V.clone())) for a in attns]
+    assert isinstance(pasts[1][0], CompressedArena) and not isinstance(pasts[0][0], CompressedArena)
+    for step in range(262):
+        qn = torch.randn(bsz, hq, 1, D, device=DEV).half()
+        kn = torch.randn(bsz, hkv, 1, D, device=DEV).half()
+        vn = torch.randn(bsz, hkv, 1, D, device=DEV).half()
+        outs = []
+        for i in (0, 1):
+            o, pasts[i] = attns[i].decode(qn, kn, vn, pasts[i])
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]), f"step {step}"
+    assert pasts[0][4] == pasts[1][4] == 512 and pasts[1][0].tokens == 512
+    ref = pasts[1][0].to_reference()
+    assert torch.equal(ref[0].flatten(), pasts[0][0][0].flatten()) and torch.equal(ref[1].flatten(), pasts[0][0][1].flatten())
+
+
+def test_view_argument_checks():
+    from mustafar_amd import _lib
+    from mustafar_amd.cache import CompressedArena
+    L = _lib.load()
+    arena = CompressedArena.from_pruned(_pruned(2, 128, 0.7, 9), "key", cap_tokens=256)
+    x = _pruned(2, 256, 0.7, 11)
+    st = torch.cuda.current_stream().cuda_stream
+    tot = torch.empty(2, dtype=torch.int64, device=DEV)
+    # 128 + 256 tokens do not fit rows of 256 tokens: rejected on the host, nothing launched
+    assert L.mustafar_cache_append_bitmap_key(st, x.data_ptr(), 2, 256, 128, arena.view_ptr(), 128, tot.data_ptr()) == 1
+    assert L.mustafar_cache_append_bitmap_key(st, x.data_ptr(), 2, 256, 128, arena.view_ptr(), 100, tot.data_ptr()) == 1   # % 64
+    assert L.mustafar_cache_append_pack_key(st, x.data_ptr(), 2, 256, 128, None, 128) == 1

@@ -44,6 +44,21 @@ def test_cabi_library_exports_every_declared_symbol():
     assert L.mustafar_value_pick_split_k(128, 1, 64, 1, 1) == 1
 
 
+def test_cache_view_strides_are_validated_without_a_gpu():
+    """mustafar_decode_attention_view rejects head strides shorter than the tokens in use (host check, no launch)."""
+    from mustafar_amd import _lib
+    L = _lib.load()
+    one = 8   # never dereferenced: validation fails first
+    T = 128
+    ok_args = (one, one, one, None, None, 1, 64, one, T + 64, one, one, 1, T, 4, 1, ctypes.c_float(11.3), None)
+    short = _lib.CacheView(one, one, one, one, 2 * T - 1, 0)
+    good = _lib.CacheView(one, one, one, one, 2 * T, 2 * T + 1)
+    assert L.mustafar_decode_attention_view(None, ctypes.byref(short), ctypes.byref(good), *ok_args) == 1
+    assert L.mustafar_decode_attention_view(None, ctypes.byref(good), None, *ok_args) == 1
+    short_idx = _lib.CacheView(one, one, one, one, 0, 2 * T)
+    assert L.mustafar_decode_attention_view(None, ctypes.byref(good), ctypes.byref(short_idx), *ok_args) == 1
+
+
 def test_invalid_arguments_are_rejected_without_a_gpu():
     """Shape errors are caught on the host before any launch (MUSTAFAR_EINVAL == 1)."""
     from mustafar_amd import _lib
