@@ -24,35 +24,70 @@ constexpr int kWaves   = 4;
 __device__ __forceinline__ bool nonzero_h(uint16_t v) { return (v & 0x7fffu) != 0; }   // -0.0 is zero, NaN is not
 
 // ------------------------------------------------------------------------------------------------ prune
-// One wave per row of 128 halfs; lane l holds elements 2l and 2l+1.  Exact k-th smallest magnitude by a
-// 15-step radix select on the fp16 magnitude bits (monotone as unsigned integers for non-NaN values).
-__global__ __launch_bounds__(kThreads) void prune_magnitude_kernel(const uint32_t* __restrict__ x,
-                                                                   uint32_t* __restrict__ out, int64_t n_rows, int kth)
+// thr = k-th smallest magnitude of a row of 128 halfs (torch.kthvalue(|x|, k), model :103); keep |x| >= thr (:107),
+// pruned entries become x * 0 = sign-preserving zero (:110).  fp16 magnitudes are monotone as unsigned integers for
+// non-NaN values, so thr is found bit by bit from the MSB: thr |= b  iff  fewer than k magnitudes are < (thr | b).
+//
+// Lane = row: one wave takes 64 rows, transposed through LDS (row stride 65 dwords: conflict-free both ways), and every
+// lane runs the 15-step search on its own row held in 64 VGPRs.  A count is a SWAR pass over the 64 packed pairs:
+// with the guard bit H = 0x8000 set in each half, (m | H) - (c | c << 16) keeps H in a half iff that magnitude >= c
+// (no borrow crosses the halves), and the set guard bits are tallied two 16-bit counters at a time.  4 plain VALU ops
+// per pair per step (sub, shift, and, add); the wave-per-row form spent ~12 SALU + 4 VALU per step and per ROW on ballots and was
+// instruction-bound at 1.7 TB/s.
+constexpr int kPruneRows  = 64;            // rows per wave
+constexpr int kPruneLd    = kD / 2 + 1;    // LDS row stride in dwords
+
+__global__ __launch_bounds__(64) void prune_magnitude_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
+                                                             int64_t n_rows, int kth)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < n_rows; row += (int64_t)gridDim.x * kWaves) {
-        const uint32_t w  = x[row * (kD / 2) + lane];
-        const uint32_t m0 = w & 0x7fffu, m1 = (w >> 16) & 0x7fffu;
-        uint32_t prefix = 0, mask = 0;
-        int k = kth;   // 1-indexed rank still to find among the candidates
-#pragma unroll
-        for (int bit = 14; bit >= 0; bit--) {
-            const uint32_t b = 1u << bit;
-            const bool c0 = ((m0 & mask) == prefix) && !(m0 & b);
-            const bool c1 = ((m1 & mask) == prefix) && !(m1 & b);
-            const int zeros = __popcll(__ballot(c0)) + __popcll(__ballot(c1));
-            if (k > zeros) {
-                k -= zeros;
-                prefix |= b;
-            }
-            mask |= b;
+    __shared__ uint32_t s_rows[kPruneRows * kPruneLd];
+    const int lane = threadIdx.x;
+    const uint32_t H = 0x80008000u, ONES = 0x00010001u;
+    for (int64_t row0 = (int64_t)blockIdx.x * kPruneRows; row0 < n_rows; row0 += (int64_t)gridDim.x * kPruneRows) {
+        const int rows = (int)((n_rows - row0) < kPruneRows ? (n_rows - row0) : kPruneRows);
+        // coalesced 16-byte loads: pass p covers rows 4p .. 4p+3 (16 lanes x 16 B per row)
+        const uint4* src = reinterpret_cast<const uint4*>(x + row0 * (kD / 2));
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < kPruneRows / 4; p++) {
+            const int r = p * 4 + (lane >> 4), c4 = lane & 15;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (r < rows) v = src[r * 16 + c4];
+            uint32_t* d = s_rows + r * kPruneLd + c4 * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        const uint32_t thr = prefix;   // == kthvalue(|x|, kth)  (llama_mustafar_kernel.py:103)
-        // keep |x| >= thr (:107); pruned entries become x * 0 = sign-preserving zero (:110)
-        const uint32_t lo = (m0 >= thr) ? (w & 0xffffu) : (w & 0x8000u);
-        const uint32_t hi = (m1 >= thr) ? (w & 0xffff0000u) : (w & 0x80000000u);
-        out[row * (kD / 2) + lane] = lo | hi;
+        __syncthreads();
+        uint32_t wh[kD / 2];   // magnitudes with the guard bits set (the signs stay behind in LDS)
+#pragma unroll
+        for (int j = 0; j < kD / 2; j++) wh[j] = s_rows[lane * kPruneLd + j] | H;
+        // bit-by-bit search of the k-th smallest magnitude
+        uint32_t thr = 0;
+#pragma unroll 1
+        for (int bit = 14; bit >= 0; bit--) {
+            const uint32_t c = thr | (1u << bit);
+            const uint32_t cc = c | (c << 16);
+            uint32_t ge = 0;   // two 16-bit counters: magnitudes >= c among the low / high halves
+#pragma unroll
+            for (int j = 0; j < kD / 2; j++) ge += ((wh[j] - cc) >> 15) & ONES;
+            const int below = kD - (int)((ge & 0xffffu) + (ge >> 16));
+            if (below < kth) thr = c;
+        }
+        // keep |x| >= thr, else the sign bit alone
+        const uint32_t tt = thr | (thr << 16);
+#pragma unroll
+        for (int j = 0; j < kD / 2; j++) {
+            const uint32_t k = ((wh[j] - tt) >> 15) & ONES;   // 1 per half that stays
+            const uint32_t keep = (k << 16) - k;               // 0xffff per half that stays
+            s_rows[lane * kPruneLd + j] &= keep | H;
+        }
+        __syncthreads();
+        uint4* dst = reinterpret_cast<uint4*>(out + row0 * (kD / 2));
+#pragma unroll 4
+        for (int p = 0; p < kPruneRows / 4; p++) {
+            const int r = p * 4 + (lane >> 4), c4 = lane & 15;
+            const uint32_t* d = s_rows + r * kPruneLd + c4 * 4;
+            if (r < rows) dst[r * 16 + c4] = make_uint4(d[0], d[1], d[2], d[3]);
+        }
     }
 }
 
@@ -69,9 +104,29 @@ struct Rows {
 // grid: x = token block (64 tokens), y = head.  Writes the 128 bitmaps of the block and the raw padded
 // counts (half2 units) into accum[h][tile + 1]; the scan kernel turns them into the exclusive prefix.
 
+// The 128 raw counts of a token block (threads 0..127 hold one each) -> inclusive prefix inside the block, written to
+// accum[...][tile + 1], and the block's total to blk_total.  Two waves: wave scan + the first wave's total.
+__device__ __forceinline__ void block_prefix_store(int32_t cnt, int32_t* __restrict__ accum_row, int64_t tile_in_row,
+                                                   int32_t* __restrict__ blk_total_slot, int32_t* s_tot)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t v = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    if (threadIdx.x == 63) *s_tot = v;
+    __syncthreads();
+    if (wave == 1) v += *s_tot;
+    if (threadIdx.x < kD) accum_row[tile_in_row + 1] = v;
+    if (threadIdx.x == kD - 1) *blk_total_slot = v;
+}
+
 // V: tile (tb, half, r) = channels half*64..+63 of token tb*64+r (compression.py:87-97); lane = channel.
 __global__ __launch_bounds__(kThreads) void bitmap_value_kernel(const uint16_t* __restrict__ x, int t, int64_t* __restrict__ bmp,
-                                                                int32_t* __restrict__ accum, Rows rows)
+                                                                int32_t* __restrict__ accum, int32_t* __restrict__ blk_total,
+                                                                Rows rows)
 {
     __shared__ uint64_t s_bmp[kD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -87,12 +142,15 @@ __global__ __launch_bounds__(kThreads) void bitmap_value_kernel(const uint16_t* 
         }
     }
     __syncthreads();
+    __shared__ int32_t s_tot;
+    int32_t cnt = 0;
+    const int64_t tile = (int64_t)tb * kD + (threadIdx.x & (kD - 1));
     if (threadIdx.x < kD) {
         const uint64_t m = s_bmp[threadIdx.x];
-        const int64_t tile = (int64_t)tb * kD + threadIdx.x;
         bmp[h * rows.bmp_stride + rows.tile0 + tile] = (int64_t)m;
-        accum[h * rows.idx_stride + rows.tile0 + tile + 1] = ((__popcll(m) + 7) & ~7) >> 1;   // compression.py:46-48
+        cnt = ((__popcll(m) + 7) & ~7) >> 1;   // compression.py:46-48
     }
+    block_prefix_store(cnt, accum + h * rows.idx_stride + rows.tile0, tile, blk_total + (int64_t)h * gridDim.x + tb, &s_tot);
 }
 
 // K: tile (tb, d) = tokens tb*64..+63 of channel d (compression.py:32-36 on the transposed input); lane = token.
@@ -118,7 +176,8 @@ __device__ __forceinline__ uint16_t block_elem(const uint32_t* s_blk, int token,
 }
 
 __global__ __launch_bounds__(kThreads) void bitmap_key_kernel(const uint16_t* __restrict__ x, int t, int64_t* __restrict__ bmp,
-                                                                int32_t* __restrict__ accum, Rows rows)
+                                                                int32_t* __restrict__ accum, int32_t* __restrict__ blk_total,
+                                                                Rows rows)
 {
     __shared__ uint32_t s_blk[64 * kRowWords];
     __shared__ uint64_t s_bmp[kD];
@@ -131,28 +190,36 @@ __global__ __launch_bounds__(kThreads) void bitmap_key_kernel(const uint16_t* __
         if (lane == 0) s_bmp[d] = m;
     }
     __syncthreads();
+    __shared__ int32_t s_tot;
+    int32_t cnt = 0;
+    const int64_t tile = (int64_t)tb * kD + (threadIdx.x & (kD - 1));
     if (threadIdx.x < kD) {
         const uint64_t m = s_bmp[threadIdx.x];
-        const int64_t tile = (int64_t)tb * kD + threadIdx.x;
         bmp[h * rows.bmp_stride + rows.tile0 + tile] = (int64_t)m;
-        accum[h * rows.idx_stride + rows.tile0 + tile + 1] = ((__popcll(m) + 7) & ~7) >> 1;
+        cnt = ((__popcll(m) + 7) & ~7) >> 1;
     }
+    block_prefix_store(cnt, accum + h * rows.idx_stride + rows.tile0, tile, blk_total + (int64_t)h * gridDim.x + tb, &s_tot);
 }
 
 // ------------------------------------------------------------------------------------------------ scan
-// accum[h][0] = 0, accum[h][i+1] = sum of raw counts [0..i]  (torch.cumsum + cat, compression.py:294-298).
-// One workgroup per head walks the tiles 256 at a time with a running carry.  Append mode (rows.tile0 > 0): the walk
-// starts at the head's entry tile0, which already holds the total of the tiles in use (model :352-360).
-__global__ __launch_bounds__(kThreads) void scan_counts_kernel(int32_t* __restrict__ accum, int64_t tiles,
-                                                               int64_t* __restrict__ totals, Rows rows)
+// accum[h][0] = 0, accum[h][i+1] = sum of raw counts [0..i]  (torch.cumsum + cat, compression.py:294-298), in three
+// parallel pieces: the bitmap kernels leave the inclusive prefix INSIDE each 64-token block and the block totals;
+// block_scan_kernel (one workgroup per head) turns the totals into every block's base; block_fixup_kernel (one
+// workgroup per block) adds the base.  Append mode (rows.tile0 > 0): the head's entry tile0 already holds the total of
+// the tiles in use (model :352-360) and is the first base.
+__global__ __launch_bounds__(kThreads) void block_scan_kernel(int32_t* __restrict__ blk_total, int ntb,
+                                                              int32_t* __restrict__ accum, int64_t* __restrict__ totals,
+                                                              Rows rows)
 {
     __shared__ int32_t s_wave[kWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* bt = blk_total + (int64_t)blockIdx.x * ntb;
     int32_t* a = accum + (int64_t)blockIdx.x * rows.idx_stride + rows.tile0;
     int32_t carry = rows.tile0 ? a[0] : 0;
-    for (int64_t base = 0; base < tiles; base += kThreads) {
-        const int64_t i = base + threadIdx.x;
-        int32_t v = (i < tiles) ? a[i + 1] : 0;
+    for (int base = 0; base < ntb; base += kThreads) {
+        const int i = base + threadIdx.x;
+        const int32_t own = (i < ntb) ? bt[i] : 0;
+        int32_t v = own;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {   // inclusive scan inside the wave
             const int32_t u = __shfl_up(v, o);
@@ -162,15 +229,24 @@ __global__ __launch_bounds__(kThreads) void scan_counts_kernel(int32_t* __restri
         __syncthreads();
         int32_t add = carry;
         for (int w = 0; w < wave; w++) add += s_wave[w];
-        const int32_t blk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        if (i < tiles) a[i + 1] = v + add;
-        carry += blk_total;
+        const int32_t blk = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (i < ntb) bt[i] = v - own + add;   // exclusive: the base of block i
+        carry += blk;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         if (rows.tile0 == 0) a[0] = 0;
         totals[blockIdx.x] = 2 * (int64_t)carry;   // halfs in this head's stream (compression.py:302)
     }
+}
+
+// grid: x = token block, y = head; 128 threads.
+__global__ __launch_bounds__(kD) void block_fixup_kernel(const int32_t* __restrict__ blk_base, int32_t* __restrict__ accum,
+                                                         Rows rows)
+{
+    const int tb = blockIdx.x, h = blockIdx.y;
+    const int32_t base = blk_base[(int64_t)h * gridDim.x + tb];
+    accum[h * rows.idx_stride + rows.tile0 + (int64_t)tb * kD + threadIdx.x + 1] += base;
 }
 
 // head_off[h] = exclusive prefix of totals (compression.py:303-304), head_off[B'] = grand total.  In place.
@@ -245,14 +321,20 @@ int bitmap_common(bool key, void* stream, const void* x, int Bp, int t, int D, i
 {
     if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || !totals) return MUSTAFAR_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(t / 64, Bp);
-    const int64_t tiles = (int64_t)t * kD / 64;
+    const int ntb = t / 64;
+    const dim3 grid(ntb, Bp);
     auto xs = static_cast<const uint16_t*>(x);
-    if (key) bitmap_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, rows);
-    else     bitmap_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, rows);
-    scan_counts_kernel<<<Bp, kThreads, 0, st>>>(accum, tiles, totals, rows);
+    // block totals / bases [B'][ntb]: stream-ordered scratch, freed behind the last kernel that reads it
+    int32_t* blk = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void**>(&blk), sizeof(int32_t) * (size_t)Bp * ntb, st) != hipSuccess) return (int)hipGetLastError();
+    if (key) bitmap_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, blk, rows);
+    else     bitmap_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, blk, rows);
+    block_scan_kernel<<<Bp, kThreads, 0, st>>>(blk, ntb, accum, totals, rows);
+    block_fixup_kernel<<<grid, kD, 0, st>>>(blk, accum, rows);
     if (exclusive_prefix) head_offsets_kernel<<<1, 64, 0, st>>>(totals, Bp);
-    return (int)hipGetLastError();
+    const int err = (int)hipGetLastError();
+    (void)hipFreeAsync(blk, st);
+    return err;
 }
 
 int pack_common(bool key, void* stream, const void* x, int Bp, int t, int D, const int32_t* accum,
@@ -289,9 +371,9 @@ int mustafar_prune_magnitude(void* stream, const void* x, void* out, int64_t n_r
 {
     if (D != kD || kth < 1 || kth > D || n_rows < 0 || !x || !out) return MUSTAFAR_EINVAL;
     if (n_rows == 0) return 0;
-    const int64_t blocks = (n_rows + kWaves - 1) / kWaves;
-    const unsigned grid = (unsigned)(blocks < 16384 ? blocks : 16384);
-    prune_magnitude_kernel<<<grid, kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+    const int64_t blocks = (n_rows + kPruneRows - 1) / kPruneRows;
+    const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+    prune_magnitude_kernel<<<grid, 64, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const uint32_t*>(x), static_cast<uint32_t*>(out), n_rows, kth);
     return (int)hipGetLastError();
 }
