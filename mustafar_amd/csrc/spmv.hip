@@ -1177,16 +1177,16 @@ inline int key_split(int ntb, int gy)
     // tools/wave_trace.py): then a wave's latency chain, not throughput, sets the time, and two waves per block halve it.
     return ((int64_t)((ntb + kWaves - 1) / kWaves) * gy <= 2048) ? 2 : 1;
 }
-// MUSTAFAR_WINDOW=rows keeps the dense-window work of the fused path inside the softmax / finish row kernels
-// (the form used when T == 0) instead of window workgroups in the SpMV launches.
-int g_window_rows = -1;
-inline bool window_in_row_kernels()
+// MUSTAFAR_WINDOW=rows keeps the dense-window work of the fused path inside the softmax / finish row kernels (the form
+// used when T == 0) instead of window workgroups in the SpMV launches; =key / =value lets only that side ride.
+int g_window_mode = -1;   // bit 0: key side rides, bit 1: value side rides
+inline int window_ride_mask()
 {
-    if (g_window_rows < 0) {
+    if (g_window_mode < 0) {
         const char* e = getenv("MUSTAFAR_WINDOW");
-        g_window_rows = (e && e[0] == 'r') ? 1 : 0;
+        g_window_mode = !e ? 3 : e[0] == 'r' ? 0 : e[0] == 'k' ? 1 : e[0] == 'v' ? 2 : 3;
     }
-    return g_window_rows == 1;
+    return g_window_mode;
 }
 int g_engine = -1;
 inline int fma_engine()
@@ -1410,14 +1410,14 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     auto vnew = static_cast<const h16*>(v_new);
     // With a compressed part the dense-window work rides in the two SpMV launches (window workgroups); without one
     // (T == 0) the two row kernels do it themselves.
-    const bool ride = T > 0 && !window_in_row_kernels();
+    const bool ride_k = T > 0 && (window_ride_mask() & 1), ride_v = T > 0 && (window_ride_mask() & 2);
     if (T > 0) {
-        const WinArgs kw = ride ? WinArgs{kwin, knew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
+        const WinArgs kw = ride_k ? WinArgs{kwin, knew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
         launch_key(st, kc.bmp, static_cast<const unsigned char*>(kc.nz), kc.idx, kc.nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores, kw,
                    prof ? g_prof.ev[4 * g_prof.n] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr, kc.bmp_head_stride,
                    kc.idx_head_stride);
     }
-    window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride ? nullptr : kwin, ride ? nullptr : knew, sc,
+    window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride_k ? nullptr : kwin, ride_k ? nullptr : knew, sc,
                                                                T, ld_scores, window_len, window_capacity, groups,
                                                                (float)(1.0 / (double)sqrt_d), window_len_extra);
     float* ws = static_cast<float*>(workspace);
@@ -1429,14 +1429,14 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
         auto nz = static_cast<const unsigned char*>(vc.nz);
         h16* no_out = nullptr;
         uint32_t* no_flags = nullptr;
-        const WinArgs vw = ride ? WinArgs{vwin, vnew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
-        if (ride) nwin_slabs = (window_capacity + kValueWinChunk - 1) / kValueWinChunk;
+        const WinArgs vw = ride_v ? WinArgs{vwin, vnew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
+        if (ride_v) nwin_slabs = (window_capacity + kValueWinChunk - 1) / kValueWinChunk;
         launch_value(st, gv, vc.bmp, nz, vc.idx, vc.nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores, vw,
                      prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, vc.bmp_head_stride,
                      vc.idx_head_stride);
         if (prof) g_prof.n++;
     }
-    value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S + nwin_slabs, sc, ld_scores, T, ride ? nullptr : vwin, ride ? nullptr : vnew,
+    value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S + nwin_slabs, sc, ld_scores, T, ride_v ? nullptr : vwin, ride_v ? nullptr : vnew,
                                                     window_len, window_capacity, static_cast<h16*>(out), Batch_Size, groups,
                                                     window_len_extra);
     return (int)hipGetLastError();
