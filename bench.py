@@ -246,7 +246,7 @@ def main():
         dt, (key_us, val_us, n_key) = timed(a.api, a.steps, a.warmup)
     n_val = n_key
     API_NOTE = {
-        "fused": "mustafar_decode_attention (C ABI extension): key SpMV -> window scores + softmax -> value SpMV -> combine + window p.V, one call per layer"
+        "fused": "mustafar_decode_attention (C ABI extension): key SpMV (+ window scores) -> softmax -> value SpMV (+ window p.V partials) -> sum, one call per layer"
                  + ("" if a.no_graph else "; the whole step captured once in a hipGraph and replayed"),
         "native": "the two reference entry points with un-padded (N=1) operands and a flat stream; PyTorch glue between them",
         "reference": "exact reference call sequence: q/p zero-padded to 8 rows, torch.cat of per-head streams per call, 8-row outputs, PyTorch glue",

@@ -7,9 +7,9 @@
 //   * The reference decompresses every tile into a dense shared-memory tile and runs tensor-core MMA
 //     against a query padded to 8 rows (7/8 of the MMA work is padding), once per q-head.
 //   * Here nothing dense is ever materialised and no matrix core is used: the path is HBM-bound.
-//     One wave64 owns a 64-token block of one kv-head = 128 consecutive tiles whose packed non-zeros are
-//     ONE contiguous byte range of the stream.  The range is copied with 16-byte coalesced loads into a
-//     wave-private LDS window (4 chunks of 32 tiles, next chunk prefetched in registers).  For each tile
+//     One wave64 (or two, one per half) owns a 64-token block of one kv-head = 128 consecutive tiles whose
+//     packed non-zeros are ONE contiguous byte range of the stream.  The range is copied with 16-byte coalesced
+//     loads into a wave-private LDS window (chunks of 32 tiles, next chunk prefetched in registers).  For each tile
 //     the 64-bit bitmap lives in an SGPR pair (scalar load): bit-reversed, it is at once the lane mask of
 //     the tile and the input of v_mbcnt, which gives every lane the rank of its element in the packed
 //     stream; one ds_read_u16 fetches the value and v_fma_mix_f32 accumulates in fp32.

@@ -17,7 +17,7 @@ compressed_length, kv_seq_len) (:445), k_compressed = [bitmaps, idxs, nzs(list p
 one flat tensor beside the list, so nothing is re-copied per step.
 `api="fused"` replaces the PyTorch glue between the two SpMVs by `mustafar_decode_attention` (C ABI extension):
 the local window lives in a preallocated buffer that is appended in place, and one call per layer launches
-key SpMV -> window scores + softmax -> value SpMV -> combine + window p.V.  All three produce the same output.
+key SpMV (+ window scores) -> softmax -> value SpMV (+ window p.V partials) -> sum.  All three produce the same output.
 """
 from __future__ import annotations
 
