@@ -123,3 +123,37 @@ def test_fused_decode_under_graph_replay():
     K_all, V_all = torch.cat([K_all, k1], 2), torch.cat([V_all, v1], 2)
     out2, past = attn.decode_fused(qn, k1, v1, past)
     torch.testing.assert_close(out2.float(), _dense_reference(qn, K_all, V_all, 256, 0.7, 0.7, hq // hkv), rtol=4e-3, atol=2e-3)
+
+
+_ALT_FORMS = r"""
+import math, sys, torch
+sys.path.insert(0, {root!r})
+from mustafar_amd.hook import MustafarAttention, MustafarConfig
+from tests.test_gpu_hook import _dense_reference
+torch.manual_seed(11)
+dev, bsz, hq, hkv, D, L0 = "cuda:0", 2, 8, 2, 128, 600
+cfg = MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, api="fused")
+attn = MustafarAttention(cfg)
+K = torch.randn(bsz, hkv, L0, D, device=dev).half(); V = torch.randn(bsz, hkv, L0, D, device=dev).half()
+past = attn.to_fused(attn.build_cache(K.clone(), V.clone()))
+for step in range(6):
+    qn, kn, vn = (torch.randn(bsz, h, 1, D, device=dev).half() for h in (hq, hkv, hkv))
+    K, V = torch.cat([K, kn], 2), torch.cat([V, vn], 2)
+    C = past[4]
+    out, past = attn.decode(qn, kn, vn, past)
+    want = _dense_reference(qn, K, V, C, 0.7, 0.7, hq // hkv)
+    torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
+print("alt-form ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{"MUSTAFAR_WINDOW": "rows"}, {"MUSTAFAR_WINDOW": "key"}, {"MUSTAFAR_VALUE_SPLIT": "1"},
+                                 {"MUSTAFAR_KEY_SPLIT": "1"}, {"MUSTAFAR_KEY_SPLIT": "2", "MUSTAFAR_FMA_ENGINE": "mfma"}])
+def test_alternative_kernel_forms_in_a_child_process(env):
+    """The launch-shape switches are read once per process: each non-default form decodes a few steps in a child
+    process and is held against dense attention like the default form."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", _ALT_FORMS.format(root=root)], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "alt-form ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
