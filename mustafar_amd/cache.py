@@ -59,8 +59,12 @@ class CompressedArena:
 
     def _grow(self, cap_tokens: int, nz_cap: int):
         """Re-house the cache with larger rows / regions (amortised: capacities grow geometrically)."""
+        self._rehouse(max(cap_tokens, self.cap_tokens), max(nz_cap, self.nz_cap))
+
+    def _rehouse(self, cap_tokens: int, nz_cap: int):
         old = (self.bmp, self.idx, self.nz, self.used.clone(), self.tokens)
-        self._alloc(max(cap_tokens, self.cap_tokens), max(nz_cap, self.nz_cap))
+        assert cap_tokens >= self.tokens and nz_cap >= (int(self.used.max()) if self.tokens else 0)
+        self._alloc(cap_tokens, nz_cap)
         o_bmp, o_idx, o_nz, used, tokens = old
         t = tokens * self.TILES_PER_TOKEN
         self.bmp[:, :t] = o_bmp[:, :t]
@@ -99,19 +103,24 @@ class CompressedArena:
 
     # ---- conversion ------------------------------------------------------------------------------------------
     @classmethod
-    def from_pruned(cls, x: torch.Tensor, which: str, cap_tokens: Optional[int] = None, headroom: float = 1.25) -> "CompressedArena":
-        """Compress x [B', t, 128] (already pruned) into a new arena sized for `cap_tokens` (default: t + 1024)."""
+    def from_pruned(cls, x: torch.Tensor, which: str, cap_tokens: Optional[int] = None, headroom: float = 1.08) -> "CompressedArena":
+        """Compress x [B', t, 128] (already pruned) into a new arena sized for `cap_tokens` (default: t + 1024) with
+        stream regions of `headroom` x the measured halfs per token."""
         heads, t, _ = x.shape
         cap = _round_up(cap_tokens if cap_tokens else t + 1024, 256)
-        # a first guess for the stream regions: dense would be 128 halfs per token; kept values + padding are well under
-        # half of that at the sparsities of interest -- append() re-houses if the guess is short
-        a = cls(heads, which, x.device, cap, _round_up(int(cap * 64 * headroom), 8))
+        # first pass into rows of exactly t tokens and a generous guess for the streams (dense would be 128 halfs per
+        # token), then re-house at the measured size: the transient is freed, the resident footprint is tight
+        a = cls(heads, which, x.device, _round_up(t, 64), _round_up(t * 72 + 1024, 8))
         a.append(x)
+        per_token = float(a.used.max()) / max(t, 1)
+        nz_cap = _round_up(int(per_token * cap * headroom) + 1024, 8)
+        if cap != a.cap_tokens or nz_cap != a.nz_cap:
+            a._rehouse(cap, nz_cap)
         return a
 
     @classmethod
     def from_reference(cls, compressed: list, which: str, tokens: int, cap_tokens: Optional[int] = None,
-                       headroom: float = 1.25) -> "CompressedArena":
+                       headroom: float = 1.08) -> "CompressedArena":
         """Re-house a reference-layout cache `[bitmaps, idxs, nzs, nz_offset]` holding `tokens` tokens per head."""
         bmp, idx, nzs, _ = compressed
         heads = len(nzs)

@@ -670,15 +670,17 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     MUSTAFAR_TRACE_BEGIN(1);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int)blockIdx.y < wa.rows) {   // fused decode only (N == 1): window scores
-        const int task = blockIdx.y * gridDim.x + blockIdx.x;
-        if (task < (int)(gridDim.y - wa.rows) * wa.nchunks)
+    const int wrows = wa.rows < 0 ? -wa.rows : wa.rows;            // window rows lead (rows > 0) or trail (rows < 0) the grid
+    const int wy = wa.rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
+    if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window scores
+        const int task = wy * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wrows) * wa.nchunks)
             key_window_wg<G>(smem, q, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, out, T, ldc,
                              groups, task);
         MUSTAFAR_TRACE_END();
         return;
     }
-    const int by = blockIdx.y - wa.rows;
+    const int by = blockIdx.y - (wa.rows > 0 ? wa.rows : 0);
     const int hb_per_kv = groups / G;
     const int kvh = by / hb_per_kv;
     const int bh0 = kvh * groups + (by % hb_per_kv) * G;
@@ -869,15 +871,17 @@ __global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
     static_assert(NW * kStageBytes >= NW * 2 * 4 * 64 * 4, "reduce buffer must fit in the stage area");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int)blockIdx.y < wa.rows) {   // fused decode only (N == 1): window p.V -> slabs gridDim.x ..
-        const int task = blockIdx.y * gridDim.x + blockIdx.x;
-        if (task < (int)(gridDim.y - wa.rows) * wa.nchunks)
+    const int wrows = wa.rows < 0 ? -wa.rows : wa.rows;            // window rows lead (rows > 0) or trail (rows < 0) the grid
+    const int wy = wa.rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
+    if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window p.V -> slabs gridDim.x ..
+        const int task = wy * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wrows) * wa.nchunks)
             value_window_wg<G, NW>(smem, p, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, ws,
                                    (int64_t)BH * kD, gridDim.x, T, ldb, groups, task);
         MUSTAFAR_TRACE_END();
         return;
     }
-    const int by = blockIdx.y - wa.rows;
+    const int by = blockIdx.y - (wa.rows > 0 ? wa.rows : 0);
     const int hb_per_kv = groups / G;
     const int kvh = by / hb_per_kv;
     const int bh0 = kvh * groups + (by % hb_per_kv) * G;
@@ -1188,6 +1192,17 @@ inline int window_ride_mask()
     }
     return g_window_mode;
 }
+// MUSTAFAR_WINDOW_POS=last|klast|vlast puts the window workgroups of both / the key / the value launch behind the SpMV
+// rows of the grid instead of in front of them.
+int g_window_last = -1;   // bit 0: key launch, bit 1: value launch
+inline bool window_rows_last(int side)
+{
+    if (g_window_last < 0) {
+        const char* e = getenv("MUSTAFAR_WINDOW_POS");
+        g_window_last = !e ? 0 : e[0] == 'l' ? 3 : e[0] == 'k' ? 1 : e[0] == 'v' ? 2 : 0;
+    }
+    return (g_window_last >> side) & 1;
+}
 int g_engine = -1;
 inline int fma_engine()
 {
@@ -1224,6 +1239,7 @@ void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, co
         wa.nchunks = (wa.w_cap + kKeyWinChunk - 1) / kKeyWinChunk;
         wa.rows = (gy * wa.nchunks + (int)grid.x - 1) / (int)grid.x;
         grid.y += wa.rows;
+        if (window_rows_last(0)) wa.rows = -wa.rows;
     }
 #define MUSTAFAR_LK(GG, MFF)                                                                                                   \
     do {                                                                                                                       \
@@ -1269,6 +1285,7 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
         wa.nchunks = (wa.w_cap + kValueWinChunk - 1) / kValueWinChunk;
         wa.rows = ((int)grid.y * wa.nchunks + (int)grid.x - 1) / (int)grid.x;
         grid.y += wa.rows;
+        if (window_rows_last(1)) wa.rows = -wa.rows;
     }
 #define MUSTAFAR_LV(GG, MFF)                                                                                                   \
     do {                                                                                                                       \
