@@ -148,7 +148,8 @@ print("alt-form ok")
 
 
 @pytest.mark.parametrize("env", [{"MUSTAFAR_WINDOW": "rows"}, {"MUSTAFAR_WINDOW": "key"}, {"MUSTAFAR_VALUE_SPLIT": "1"},
-                                 {"MUSTAFAR_KEY_SPLIT": "1"}, {"MUSTAFAR_KEY_SPLIT": "2", "MUSTAFAR_FMA_ENGINE": "mfma"}])
+                                 {"MUSTAFAR_KEY_SPLIT": "1"}, {"MUSTAFAR_KEY_SPLIT": "2", "MUSTAFAR_FMA_ENGINE": "mfma"},
+                                 {"MUSTAFAR_WINDOW_POS": "first"}, {"MUSTAFAR_WINDOW_POS": "last"}])
 def test_alternative_kernel_forms_in_a_child_process(env):
     """The launch-shape switches are read once per process: each non-default form decodes a few steps in a child
     process and is held against dense attention like the default form."""
