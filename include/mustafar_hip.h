@@ -101,7 +101,8 @@ int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int
  *   scores       [Batch_Size, ld_scores] scratch (scores, then probabilities); ld_scores >= T + window_len, % 8 == 0
  *   out          [Batch_Size, 128]
  *   workspace    mustafar_decode_workspace_bytes() bytes (fp32 partial slabs); Split_K as for Value_SplitK_API
- *   T            compressed tokens (multiple of 64, 0 allowed: window only); sqrt_d = sqrt(head_dim)
+ *   T            compressed tokens (multiple of 64, 0 allowed: window only; rows longer than 32768 take a streaming
+ *                softmax); sqrt_d = sqrt(head_dim)
  *   window_len_extra  NULL, or a device int added to window_len inside the kernels (clamped to the capacity):
  *                lets a captured hipGraph of a whole decode step be replayed while the windows keep growing;
  *                advance it once per step with mustafar_counter_add().  ld_scores must then cover the capacity.

@@ -1104,6 +1104,45 @@ __global__ __launch_bounds__(kGlueThreads) void window_softmax_kernel(
     for (int w = tid; w < w_len; w += kGlueThreads) row[T + w] = (h16)(__expf(scaled(wsc[w], inv_sqrt_d) - m) * inv);
 }
 
+// Rows longer than the register form holds (T > 32768): the same softmax as three passes over the row in global memory
+// (max, denominator, write); the window scores must already be in the row (T > 0: the key launch's window workgroups).
+__global__ __launch_bounds__(kGlueThreads) void long_softmax_kernel(h16* __restrict__ scores, int T, int ld, int w_len, int w_cap,
+                                                                    float inv_sqrt_d, const int* __restrict__ w_extra)
+{
+    __shared__ float sh[kGlueWaves];
+    if (w_extra) w_len = min(w_len + *w_extra, w_cap);
+    const int tid = threadIdx.x;
+    h16* row = scores + (int64_t)blockIdx.x * ld;
+    const int nvec = T / 8, n = T + w_len;
+    float m = -INFINITY;
+    for (int v = tid; v < nvec; v += kGlueThreads) {
+        Vec8 x;
+        x.u = reinterpret_cast<const uint4*>(row)[v];
+#pragma unroll
+        for (int j = 0; j < 8; j++) m = fmaxf(m, scaled(x.h[j], inv_sqrt_d));
+    }
+    for (int i = T + tid; i < n; i += kGlueThreads) m = fmaxf(m, scaled(row[i], inv_sqrt_d));
+    m = block_reduce<kGlueWaves>(m, true, sh);
+    float l = 0.f;
+    for (int v = tid; v < nvec; v += kGlueThreads) {
+        Vec8 x;
+        x.u = reinterpret_cast<const uint4*>(row)[v];
+#pragma unroll
+        for (int j = 0; j < 8; j++) l += __expf(scaled(x.h[j], inv_sqrt_d) - m);
+    }
+    for (int i = T + tid; i < n; i += kGlueThreads) l += __expf(scaled(row[i], inv_sqrt_d) - m);
+    l = block_reduce<kGlueWaves>(l, false, sh);
+    const float inv = 1.f / l;
+    for (int v = tid; v < nvec; v += kGlueThreads) {
+        Vec8 x, o;
+        x.u = reinterpret_cast<const uint4*>(row)[v];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o.h[j] = (h16)(__expf(scaled(x.h[j], inv_sqrt_d) - m) * inv);
+        reinterpret_cast<uint4*>(row)[v] = o.u;
+    }
+    for (int i = T + tid; i < n; i += kGlueThreads) row[i] = (h16)(__expf(scaled(row[i], inv_sqrt_d) - m) * inv);
+}
+
 __global__ void counter_add_kernel(int* ctr, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += delta; }
 
 // out[bh, c] = fp16( sum_s ws[s, bh, c] + sum_w p[bh, T + w] * V_window[kvh, w, c] )   (:315-317), and window append (:309).
@@ -1407,7 +1446,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
 {
     const int groups = num_key_value_groups;
     if (T < 0 || (T & 63) || groups < 1 || Batch_Size < 1 || Batch_Size % groups || window_len < 1 ||
-        window_len > window_capacity || window_capacity > kMaxWindow || T > kMaxRowVecs * kGlueThreads * 8 ||
+        window_len > window_capacity || window_capacity > kMaxWindow ||
         ld_scores < T + (window_len_extra ? window_capacity : window_len) || (ld_scores & 7) || Split_K < 1 || !(sqrt_d > 0.f))
         return MUSTAFAR_EINVAL;
     if (!q || !k_window || !v_window || !scores || !out || !workspace) return MUSTAFAR_EINVAL;
@@ -1429,16 +1468,21 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     auto vnew = static_cast<const h16*>(v_new);
     // With a compressed part the dense-window work rides in the two SpMV launches (window workgroups); without one
     // (T == 0) the two row kernels do it themselves.
-    const bool ride_k = T > 0 && (window_ride_mask() & 1), ride_v = T > 0 && (window_ride_mask() & 2);
+    const bool long_rows = T > kMaxRowVecs * kGlueThreads * 8;   // beyond the register form of the softmax kernel
+    const bool ride_k = T > 0 && ((window_ride_mask() & 1) || long_rows), ride_v = T > 0 && (window_ride_mask() & 2);
     if (T > 0) {
         const WinArgs kw = ride_k ? WinArgs{kwin, knew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
         launch_key(st, kc.bmp, static_cast<const unsigned char*>(kc.nz), kc.idx, kc.nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores, kw,
                    prof ? g_prof.ev[4 * g_prof.n] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr, kc.bmp_head_stride,
                    kc.idx_head_stride);
     }
-    window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride_k ? nullptr : kwin, ride_k ? nullptr : knew, sc,
-                                                               T, ld_scores, window_len, window_capacity, groups,
-                                                               (float)(1.0 / (double)sqrt_d), window_len_extra);
+    if (long_rows)
+        long_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(sc, T, ld_scores, window_len, window_capacity,
+                                                                 (float)(1.0 / (double)sqrt_d), window_len_extra);
+    else
+        window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride_k ? nullptr : kwin, ride_k ? nullptr : knew, sc,
+                                                                   T, ld_scores, window_len, window_capacity, groups,
+                                                                   (float)(1.0 / (double)sqrt_d), window_len_extra);
     float* ws = static_cast<float*>(workspace);
     if (T > 0) {
         const int ntb = T / 64;

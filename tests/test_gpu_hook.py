@@ -158,3 +158,21 @@ def test_alternative_kernel_forms_in_a_child_process(env):
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-c", _ALT_FORMS.format(root=root)], env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "alt-form ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fused_decode_with_rows_longer_than_32768():
+    """Compressed length 33024 > 32768: the softmax runs in its streaming form (three passes over the row)."""
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    torch.manual_seed(5)
+    bsz, hq, hkv, D, L0 = 1, 4, 1, 128, 33024 + 40
+    attn = MustafarAttention(MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, api="fused"))
+    K = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    V = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    past = attn.to_fused(attn.build_cache(K.clone(), V.clone()))
+    assert past[4] == 33024
+    for _ in range(2):
+        qn, kn, vn = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+        K, V = torch.cat([K, kn], 2), torch.cat([V, vn], 2)
+        out, past = attn.decode(qn, kn, vn, past)
+        want = _dense_reference(qn, K, V, 33024, 0.7, 0.7, hq // hkv)
+        torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
