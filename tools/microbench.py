@@ -25,12 +25,16 @@ CFG = {  # name: (Hq, Hkv, sparsity, L, batch)
 }
 
 
-def build_cache(Bp, T, s, which, dev, gen):
+def build_cache(Bp, T, s, which, dev, gen, adversarial=False):
+    """adversarial: every kept value of a token sits in channels 0..63: V tiles of the upper half and K
+    tiles of channels 64..127 are empty, the others carry twice the usual non-zeros."""
     chunk = max(1, (1 << 26) // (T * 128))     # heads per compress call: bounds the dense temporary
     bmps, idxs, nzs = [], [], []
     for b0 in range(0, Bp, chunk):
         b1 = min(Bp, b0 + chunk)
         x = torch.randn((b1 - b0, T, 128), device=dev, generator=gen, dtype=torch.float32).half()
+        if adversarial:
+            x[:, :, 64:] *= 1e-3     # the magnitude rule then keeps only channels 0..63
         x = compression.prune_magnitude(x, s)
         conv = compression.convert_key_batched if which == "key" else compression.convert_value_batched
         b, i, n = conv(x)
@@ -61,6 +65,7 @@ def main():
     ap.add_argument("--cfg", nargs="+", default=["c2", "c3"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rows", nargs="+", type=int, default=[1, 8])
+    ap.add_argument("--adversarial", action="store_true", help="all kept values in one 64-channel half (empty + dense tiles)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev).manual_seed(42)
@@ -68,8 +73,8 @@ def main():
         Hq, Hkv, s, L, batch = CFG[name]
         T = ((L - 32) // 256) * 256
         Bp, BH, groups = batch * Hkv, batch * Hq, Hq // Hkv
-        kc = build_cache(Bp, T, s, "key", dev, gen)
-        vc = build_cache(Bp, T, s, "value", dev, gen)
+        kc = build_cache(Bp, T, s, "key", dev, gen, a.adversarial)
+        vc = build_cache(Bp, T, s, "value", dev, gen, a.adversarial)
         ws = torch.zeros(1, dtype=torch.float16, device=dev)
         meta = Bp * (2 * T * 8 + (2 * T + 1) * 4)
         for N in a.rows:
@@ -81,7 +86,7 @@ def main():
             tv = timeit(lambda: mp.mustafar_value_formulation(*vc, p, ws, 128, T, BH, groups), a.iters)
             bk = meta + 2 * kc[1].numel() + BH * 128 * 2 + BH * T * 2
             bv = meta + 2 * vc[1].numel() + BH * T * 2 + BH * 128 * 2
-            print(json.dumps(dict(cfg=name, rows=N, T=T, Bp=Bp, BH=BH, key_us=round(tk * 1e6, 2), value_us=round(tv * 1e6, 2),
+            print(json.dumps(dict(cfg=name + ("-adversarial" if a.adversarial else ""), rows=N, T=T, Bp=Bp, BH=BH, key_us=round(tk * 1e6, 2), value_us=round(tv * 1e6, 2),
                                   key_alg_MB=round(bk / 1e6, 2), value_alg_MB=round(bv / 1e6, 2),
                                   key_GBps=round(bk / tk / 1e9, 1), value_GBps=round(bv / tv / 1e9, 1))), flush=True)
         del kc, vc
