@@ -69,7 +69,7 @@ struct WaveTrace {
 #define MUSTAFAR_TRACE_END()
 #endif
 
-constexpr int kWaves      = 4;                    // waves per workgroup
+constexpr int kWaves      = 4;                    // waves per workgroup (key kernel; the value kernel defaults to kValueWaves = 8)
 constexpr int kThreads    = 64 * kWaves;
 constexpr int kChunkTiles = 32;                   // tiles staged per LDS chunk
 constexpr int kChunkBytes = kChunkTiles * 128;    // worst case: 64 halfs per tile
