@@ -326,14 +326,24 @@ int bitmap_common(bool key, void* stream, const void* x, int Bp, int t, int D, i
     auto xs = static_cast<const uint16_t*>(x);
     // block totals / bases [B'][ntb]: stream-ordered scratch, freed behind the last kernel that reads it
     int32_t* blk = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&blk), sizeof(int32_t) * (size_t)Bp * ntb, st) != hipSuccess) return (int)hipGetLastError();
+    bool pooled = true;
+    if (hipMallocAsync(reinterpret_cast<void**>(&blk), sizeof(int32_t) * (size_t)Bp * ntb, st) != hipSuccess) {
+        (void)hipGetLastError();   // no stream-ordered allocator here: plain allocation, freed after the stream drains
+        pooled = false;
+        if (hipMalloc(reinterpret_cast<void**>(&blk), sizeof(int32_t) * (size_t)Bp * ntb) != hipSuccess) return (int)hipGetLastError();
+    }
     if (key) bitmap_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, blk, rows);
     else     bitmap_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, blk, rows);
     block_scan_kernel<<<Bp, kThreads, 0, st>>>(blk, ntb, accum, totals, rows);
     block_fixup_kernel<<<grid, kD, 0, st>>>(blk, accum, rows);
     if (exclusive_prefix) head_offsets_kernel<<<1, 64, 0, st>>>(totals, Bp);
     const int err = (int)hipGetLastError();
-    (void)hipFreeAsync(blk, st);
+    if (pooled) {
+        (void)hipFreeAsync(blk, st);
+    } else {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(blk);
+    }
     return err;
 }
 
