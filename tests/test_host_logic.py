@@ -153,3 +153,13 @@ def test_compiled_extension_exposes_reference_module_surface():
     with pytest.raises(RuntimeError, match="Tensor B must be of type float16"):
         mustafar_package.mustafar_key_formulation(bmp, torch.zeros(8, dtype=torch.float16), torch.zeros(5, dtype=torch.int32),
                                                   torch.zeros(1, dtype=torch.int32), torch.zeros((1, 8, 128)), 64, 128, 1, 1)
+
+
+def test_no_read_of_an_in_flight_scalar_load_in_the_spmv_isa():
+    """The asm inner loop issues scalar loads and waits later; the generated ISA must not read (copy, spill) one of
+    those SGPRs in between -- there is no hardware interlock (tools/check_smem_hazards.py, compiles device code only)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_smem_hazards", os.path.join(ROOT, "tools", "check_smem_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Static check of the SpMV kernels' ISA: no instruction reads an SGPR that a scalar load still has in flight.
+
+The inner loop issues `s_load_dword*` inside asm statements and waits later (`s_waitcnt lgkmcnt(0)`); the compiler does not
+know those registers are pending, so nothing but our own placement keeps it from copying or spilling them (`s_mov`,
+`v_writelane`) between issue and wait -- which would read stale data without any hardware interlock.  This script compiles
+spmv.hip to assembly (device only; works without a GPU) and walks every kernel: SGPRs written by a scalar load are
+"pending" until the next `s_waitcnt` that drains lgkmcnt; any read of a pending SGPR is reported.
+
+    python tools/check_smem_hazards.py        # exit code 1 on a hazard
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "mustafar_amd", "csrc", "spmv.hip")
+
+
+def sgprs(tok):
+    """'s[8:23]' -> {8..23}; 's5' -> {5}; anything else -> empty."""
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check(asm_text):
+    hazards, kernel, pending = [], None, set()
+    loads = waits = 0
+    for ln, line in enumerate(asm_text.splitlines(), 1):
+        code = line.split(";")[0].strip()
+        if not code:
+            continue
+        if code.endswith(":") and not code.startswith("."):
+            kernel, pending = code[:-1], set()
+            continue
+        if code.startswith("."):
+            continue
+        parts = code.replace(",", " ").split()
+        op, args = parts[0], parts[1:]
+        if op.startswith("s_waitcnt"):
+            if "lgkmcnt(0)" in code or re.fullmatch(r"s_waitcnt\s+0", code):
+                pending, waits = set(), waits + 1
+            continue
+        if op.startswith("s_load_dword") or op.startswith("s_buffer_load"):
+            base = set().union(*[sgprs(a) for a in args[1:]])
+            if base & pending:
+                hazards.append((kernel, ln, code))
+            pending |= sgprs(args[0])
+            loads += 1
+            continue
+        if pending:
+            used = set().union(*[sgprs(a) for a in args]) if args else set()
+            if used & pending:
+                hazards.append((kernel, ln, code))
+    return hazards, loads, waits
+
+
+def main():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "spmv.s")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only",
+                               "-S", "-I" + os.path.join(ROOT, "include"), SRC, "-o", out], stderr=subprocess.DEVNULL)
+        hazards, loads, waits = check(open(out).read())
+    print(f"scalar loads: {loads}, draining waits: {waits}, hazards: {len(hazards)}")
+    for k, ln, code in hazards[:20]:
+        print(f"  {k}: line {ln}: {code}")
+    return 1 if hazards else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
