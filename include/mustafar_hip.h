@@ -106,13 +106,19 @@ int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int
  *   window_len_extra  NULL, or a device int added to window_len inside the kernels (clamped to the capacity):
  *                lets a captured hipGraph of a whole decode step be replayed while the windows keep growing;
  *                advance it once per step with mustafar_counter_add().  ld_scores must then cover the capacity.
+ *   attention_mask    NULL, or the hook's additive fp16 mask (models/llama_mustafar_kernel.py:293-301; the non-flash model
+ *                always passes one, :723-728): rows of >= T + window length halfs, `mask_row_stride` halfs apart, one row
+ *                per `heads_per_mask_row` consecutive score rows (the reference mask is [bsz, 1, 1, kv_len]: stride kv_len,
+ *                heads_per_mask_row = q heads).  Applied exactly as the hook does: fp16(score / sqrt(d)) + mask in fp16,
+ *                max with finfo(fp16).min, then the fp32 softmax.  Rows need no alignment.
  */
 int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k_nz, const uint32_t* k_idx,
                               const uint32_t* k_nz_offset, const uint64_t* v_bmp, const void* v_nz, const uint32_t* v_idx,
                               const uint32_t* v_nz_offset, const void* q, void* k_window, void* v_window, const void* k_new,
                               const void* v_new, int window_len, int window_capacity, void* scores, int ld_scores, void* out,
                               void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
-                              const int32_t* window_len_extra);
+                              const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
+                              int heads_per_mask_row);
 int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value_groups, int Split_K);
 
 /*
@@ -137,7 +143,8 @@ int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_ca
                                    const void* q, void* k_window, void* v_window, const void* k_new, const void* v_new,
                                    int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
                                    int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
-                                   const int32_t* window_len_extra);
+                                   const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
+                                   int heads_per_mask_row);
 
 /*
  * In-place append of t new (already pruned) tokens per head behind the `old_tokens` a view holds: the cache-append

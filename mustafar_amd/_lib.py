@@ -29,9 +29,10 @@ SIGNATURES = {
     "Value_SplitK_API": (_i32, [_vp] * 8 + [_i32] * 3 + [_vp] + [_i32] * 3),
     "mustafar_value_pick_split_k": (_i32, [_i32] * 5),
     "mustafar_value_workspace_bytes": (_i64, [_i32] * 6),
-    "mustafar_decode_attention": (_i32, [_vp] * 14 + [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_float, _vp]),
+    "mustafar_decode_attention": (_i32, [_vp] * 14 + [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_float, _vp,
+                                         _vp, _i64, _i32]),
     "mustafar_decode_attention_view": (_i32, [_vp, _view_p, _view_p] + [_vp] * 5 + [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
-                                              ctypes.c_float, _vp]),
+                                              ctypes.c_float, _vp, _vp, _i64, _i32]),
     "mustafar_cache_append_bitmap_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32, _vp]),
     "mustafar_cache_append_bitmap_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32, _vp]),
     "mustafar_cache_append_pack_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32]),

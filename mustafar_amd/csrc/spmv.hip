@@ -78,6 +78,12 @@ constexpr int kStageBytes = kChunkBytes;          // lanes whose element is zero
                                                   // No pad: 4 x 4 KiB = 16 KiB exactly, one LDS allocation granule less per workgroup
 constexpr int kD          = 128;                  // head_dim supported by this build
 constexpr int kTilesPerTb = kD;                   // tiles per 64-token block (both formats)
+// MFMA engine: row strides of the LDS coefficient tables.  Lane l reads 8 bytes of row l % 4 (ds_read_b64: bank =
+// dword address mod 64); with the natural strides (256 B / 128 B) the four rows sit on the same banks and every read
+// is a 4-way / 2-way conflict (measured 0.30 vs 1.1 wave-instructions/ns/CU).  One 16-byte granule of padding per row
+// puts the four rows on disjoint bank pairs and keeps 16-byte alignment for the fill.
+constexpr int kKeyTabStride = kD * 2 + 16;        // 272 B: [4 heads][128 channels] fp16
+constexpr int kValTabStride = 64 * 2 + 16;        // 144 B: [4 heads][64 tokens] fp16
 
 // Register image of one staged chunk (<= 4 KiB, 16-byte granules: 4 x uint4 per lane).
 struct Stage {
@@ -91,11 +97,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // masking and nothing is ever read beyond the packed stream.  `src` and `len` are wave-uniform.
 __device__ __forceinline__ Stage stage_issue(const unsigned char* __restrict__ src, uint32_t len, int lane)
 {
+#ifdef MUSTAFAR_PROBE_NOSTREAM   // timing-only build (tools/ab.py): zero records -> every stream load returns zeros without
+    const __amdgpu_buffer_rsrc_t rsrc =   // touching memory; instruction stream, waits and LDS traffic unchanged, results wrong
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), (short)0, 0, 0x00020000);
+#else
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), (short)0, (int)len, 0x00020000);
+#endif
     const int off = lane * 16;
     Stage s;
     u32x4 t;
+    // (skipping the 1-KiB pieces that lie wholly beyond the chunk's data -- a chunk is ~1.5 KiB at 70 % sparsity -- was
+    // measured in round 2: the scalar branches cost the VALU engine 2-3 %, the matrix-pipe engine nothing either way)
     t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);        s.r0 = {t.x, t.y, t.z, t.w};
     t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024, 0, 0); s.r1 = {t.x, t.y, t.z, t.w};
     t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048, 0, 0); s.r2 = {t.x, t.y, t.z, t.w};
@@ -104,7 +117,7 @@ __device__ __forceinline__ Stage stage_issue(const unsigned char* __restrict__ s
 }
 
 // Copy the register image into the wave's LDS window (the zero tail is written too: the window is 4 KiB).
-__device__ __forceinline__ void stage_commit(unsigned char* lds, const Stage& s, int lane)
+__device__ __forceinline__ void stage_commit(unsigned char* lds, const Stage& s, int lane, uint32_t /*len*/)
 {
     uint4* w = reinterpret_cast<uint4*>(lds) + lane;
     w[0]   = s.r0;
@@ -145,9 +158,25 @@ struct MetaB {         // tile metadata of one step (8 tiles) -- all SGPRs
 
 // Issue the scalar loads of the bitmaps / offsets of step S of a chunk (byte offsets are immediates).  Nothing may
 // read `m` before a metab_wait() that follows.
+#ifdef MUSTAFAR_PROBE_HOTMETA   // timing-only build: every wave reads the SAME 256 + 128 bytes of metadata (scalar-cache hits);
+__device__ uint64_t g_hot_bmp[32] = {   // ~30 % dense masks; results are wrong, the instruction stream is unchanged
+    0x1249249249249249ull, 0x2492492492492492ull, 0x4924924924924924ull, 0x9249249249249249ull, 0x1111111144444444ull, 0x0f0f00ff00f0f00full,
+    0x1249249249249249ull, 0x2492492492492492ull, 0x4924924924924924ull, 0x9249249249249249ull, 0x1111111144444444ull, 0x0f0f00ff00f0f00full,
+    0x1249249249249249ull, 0x2492492492492492ull, 0x4924924924924924ull, 0x9249249249249249ull, 0x1111111144444444ull, 0x0f0f00ff00f0f00full,
+    0x1249249249249249ull, 0x2492492492492492ull, 0x4924924924924924ull, 0x9249249249249249ull, 0x1111111144444444ull, 0x0f0f00ff00f0f00full,
+    0x1249249249249249ull, 0x2492492492492492ull, 0x4924924924924924ull, 0x9249249249249249ull, 0x1111111144444444ull, 0x0f0f00ff00f0f00full,
+    0x1249249249249249ull, 0x2492492492492492ull};
+__device__ uint32_t g_hot_idx[32] = {0, 12, 24, 36, 48, 60, 72, 84, 96, 108, 120, 132, 144, 156, 168, 180,
+                                     192, 204, 216, 228, 240, 252, 264, 276, 288, 300, 312, 324, 336, 348, 360, 372};
+#endif
+
 template <int S>
 __device__ __forceinline__ void metab_issue(MetaB& m, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx)
 {
+#ifdef MUSTAFAR_PROBE_HOTMETA
+    bmp = g_hot_bmp;
+    idx = g_hot_idx;
+#endif
     asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx8 %1, %3, %5"
                  : "=&s"(m.bm), "=&s"(m.ix)
                  : "s"(bmp), "s"(idx), "i"(S * 64), "i"(S * 32));
@@ -310,22 +339,35 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GatheredClean {
-    uint32_t t[8];    // gathered halfs, exact zero where the tile has no element in this lane
+    uint32_t t[8];    // gathered halfs (even tiles: bits 15:0, odd tiles: bits 31:16), exact zero where the tile has no element in this lane
     uint64_t a[2];    // A fragments (4 coefficient halfs of this lane's head) for tiles 0-3 and 4-7
 };
 
+// LDS byte address of the lane's element = 2 * rank + 4 * idx + adj, formed WITHOUT a scalar op per tile: the matrix-pipe
+// engine is bound by the scalar pipe (5.9 SALU against 5.7 VALU wave-instructions per tile, one of each per SIMD per
+// 4 cycles: profiles/r02_pmc_sq_c5_mfma_before.txt), so the tile's base moves to the vector side, where there is room --
+//   v_mbcnt_lo  x = popcount(mask_lo below the lane) + adj/2      (adj/2 lives in a VGPR, set once per chunk)
+//   v_mbcnt_hi  x += popcount(mask_hi below the lane)
+//   v_lshl_add  x += idx << 1                                      (idx: the SGPR the scalar load wrote, read-only)
+//   v_add       x += x                                             (full-rate VOP2)
+// The arithmetic is mod 2^32 throughout (adj may be "negative"); adj is even (16-byte aligned window, offsets * 4).
 #define MUSTAFAR_RANK(j)                                                    \
-    "s_lshl2_add_u32 %[o" #j "], %[o" #j "], %[adj]\n\t"                     \
-    "v_mbcnt_lo_u32_b32 %[x" #j "], %[l" #j "], 0\n\t"                        \
+    "v_mbcnt_lo_u32_b32 %[x" #j "], %[l" #j "], %[vadj]\n\t"                 \
     "v_mbcnt_hi_u32_b32 %[x" #j "], %[h" #j "], %[x" #j "]\n\t"               \
-    "v_lshl_add_u32 %[x" #j "], %[x" #j "], 1, %[o" #j "]\n\t"                \
+    "v_lshl_add_u32 %[x" #j "], %[o" #j "], 1, %[x" #j "]\n\t"                \
+    "v_add_u32 %[x" #j "], %[x" #j "], %[x" #j "]\n\t"                        \
     "v_mov_b32 %[t" #j "], 0\n\t"
+// even tiles land in the low half of their register (upper half zero), odd tiles in the HIGH half: on gfx950 a d16_hi
+// load zero-fills the other half (tools/ubench/probe2.hip), so a pair packs with one plain v_or_b32 (a full-rate VOP2;
+// v_lshl_or_b32 / v_perm_b32 issue at half that rate)
 #define MUSTAFAR_MLOAD(j) "s_mov_b64 exec, %[m" #j "]\n\tds_read_u16 %[t" #j "], %[x" #j "]\n\t"
+#define MUSTAFAR_MLOAD_HI(j) "s_mov_b64 exec, %[m" #j "]\n\tds_read_u16_d16_hi %[t" #j "], %[x" #j "]\n\t"
 #define MUSTAFAR_MOPS(j) [m##j] "s"(m##j), [l##j] "s"((uint32_t)m##j), [h##j] "s"((uint32_t)(m##j >> 32))
 
 // COFF: byte offset of the step's first coefficient inside a head's row of the LDS coefficient table.
+//   vadj = (LDS byte address of the window - 4 * (stream offset of its first byte)) / 2, the same in every lane
 template <int COFF>
-__device__ __forceinline__ void gather8_clean(const MetaB& m, uint32_t adj, uint32_t ctab_lane, GatheredClean& g)
+__device__ __forceinline__ void gather8_clean(const MetaB& m, uint32_t vadj, uint32_t ctab_lane, GatheredClean& g)
 {
     const uint64_t m0 = __builtin_bitreverse64(m.bm[0] | ((uint64_t)m.bm[1] << 32));
     const uint64_t m1 = __builtin_bitreverse64(m.bm[2] | ((uint64_t)m.bm[3] << 32));
@@ -335,23 +377,22 @@ __device__ __forceinline__ void gather8_clean(const MetaB& m, uint32_t adj, uint
     const uint64_t m5 = __builtin_bitreverse64(m.bm[10] | ((uint64_t)m.bm[11] << 32));
     const uint64_t m6 = __builtin_bitreverse64(m.bm[12] | ((uint64_t)m.bm[13] << 32));
     const uint64_t m7 = __builtin_bitreverse64(m.bm[14] | ((uint64_t)m.bm[15] << 32));
-    uint32_t o0 = m.ix[0], o1 = m.ix[1], o2 = m.ix[2], o3 = m.ix[3], o4 = m.ix[4], o5 = m.ix[5], o6 = m.ix[6], o7 = m.ix[7];
     uint32_t x0, x1, x2, x3, x4, x5, x6, x7;
     asm volatile(MUSTAFAR_RANK(0) MUSTAFAR_RANK(1) MUSTAFAR_RANK(2) MUSTAFAR_RANK(3)
                  MUSTAFAR_RANK(4) MUSTAFAR_RANK(5) MUSTAFAR_RANK(6) MUSTAFAR_RANK(7)
-                 MUSTAFAR_MLOAD(0) MUSTAFAR_MLOAD(1) MUSTAFAR_MLOAD(2) MUSTAFAR_MLOAD(3)
-                 MUSTAFAR_MLOAD(4) MUSTAFAR_MLOAD(5) MUSTAFAR_MLOAD(6) MUSTAFAR_MLOAD(7)
+                 MUSTAFAR_MLOAD(0) MUSTAFAR_MLOAD_HI(1) MUSTAFAR_MLOAD(2) MUSTAFAR_MLOAD_HI(3)
+                 MUSTAFAR_MLOAD(4) MUSTAFAR_MLOAD_HI(5) MUSTAFAR_MLOAD(6) MUSTAFAR_MLOAD_HI(7)
                  "s_mov_b64 exec, -1\n\t"
                  "ds_read_b64 %[a0], %[ct] offset:%[c0]\n\t"
                  "ds_read_b64 %[a1], %[ct] offset:%[c1]"
                  : [t0] "=&v"(g.t[0]), [t1] "=&v"(g.t[1]), [t2] "=&v"(g.t[2]), [t3] "=&v"(g.t[3]), [t4] "=&v"(g.t[4]),
                    [t5] "=&v"(g.t[5]), [t6] "=&v"(g.t[6]), [t7] "=&v"(g.t[7]), [a0] "=&v"(g.a[0]), [a1] "=&v"(g.a[1]),
                    [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5),
-                   [x6] "=&v"(x6), [x7] "=&v"(x7), [o0] "+s"(o0), [o1] "+s"(o1), [o2] "+s"(o2), [o3] "+s"(o3),
-                   [o4] "+s"(o4), [o5] "+s"(o5), [o6] "+s"(o6), [o7] "+s"(o7)
+                   [x6] "=&v"(x6), [x7] "=&v"(x7)
                  : MUSTAFAR_MOPS(0), MUSTAFAR_MOPS(1), MUSTAFAR_MOPS(2), MUSTAFAR_MOPS(3), MUSTAFAR_MOPS(4), MUSTAFAR_MOPS(5),
-                   MUSTAFAR_MOPS(6), MUSTAFAR_MOPS(7), [adj] "s"(adj), [ct] "v"(ctab_lane), [c0] "i"(COFF), [c1] "i"(COFF + 8)
-                 : "scc");
+                   MUSTAFAR_MOPS(6), MUSTAFAR_MOPS(7), [o0] "s"(m.ix[0]), [o1] "s"(m.ix[1]), [o2] "s"(m.ix[2]), [o3] "s"(m.ix[3]),
+                   [o4] "s"(m.ix[4]), [o5] "s"(m.ix[5]), [o6] "s"(m.ix[6]), [o7] "s"(m.ix[7]), [vadj] "v"(vadj),
+                   [ct] "v"(ctab_lane), [c0] "i"(COFF), [c1] "i"(COFF + 8));
 }
 
 __device__ __forceinline__ void gatherc_wait(GatheredClean& g)
@@ -363,7 +404,7 @@ __device__ __forceinline__ void gatherc_wait(GatheredClean& g)
 
 __device__ __forceinline__ h16x4 pack4(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3)
 {
-    const uint2 u = {t0 | (t1 << 16), t2 | (t3 << 16)};
+    const uint2 u = {t0 | t1, t2 | t3};   // t1 / t3 arrive in the high half (MUSTAFAR_MLOAD_HI)
     return __builtin_bit_cast(h16x4, u);
 }
 
@@ -375,11 +416,13 @@ __device__ __forceinline__ void fma8_mfma(const GatheredClean& g, f32x4& acc)
 
 // One staged chunk (32 tiles) on the MFMA engine; CBASE = byte offset of the chunk's first coefficient in a table row.
 template <int CBASE>
-__device__ __forceinline__ void chunk32_mfma(uint32_t adj, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx,
+__device__ __forceinline__ void chunk32_mfma(uint32_t adj_s, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx,
                                              uint32_t ctab_lane, f32x4& acc)
 {
     MetaB cur, nxt;
     GatheredClean g;
+    uint32_t adj;   // adj_s / 2 in a VGPR (one v_lshrrev per chunk)
+    asm volatile("v_lshrrev_b32 %0, 1, %1" : "=v"(adj) : "s"(adj_s));
     metab_issue<0>(cur, bmp, idx);
     metab_wait(cur);
 #define MUSTAFAR_STEP(S)                               \
@@ -468,22 +511,28 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
     const uint32_t pf = prefetch_meta<0>(bmp_t, idx_t, qw, chead, lane);
     const uint32_t bnd = bnd_load(idx_t, lane);
     uint32_t i0 = bnd_get(bnd, CB);
-    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (bnd_get(bnd, CB + 1) - i0), lane);
-    stage_commit(lds, st, lane);
+    const uint32_t len0 = 4u * (bnd_get(bnd, CB + 1) - i0);
+    Stage st = stage_issue(nz_h + 4ull * i0, len0, lane);
+    stage_commit(lds, st, lane, len0);
     prefetch_done(pf);
 #pragma unroll
     for (int c = CB; c < CB + CN; c++) {
-        uint32_t n0 = 0;
+        uint32_t n0 = 0, nlen = 0;
         if (c < CB + CN - 1) {
             n0 = bnd_get(bnd, c + 1);
-            st = stage_issue(nz_h + 4ull * n0, 4u * (bnd_get(bnd, c + 2) - n0), lane);
+            nlen = 4u * (bnd_get(bnd, c + 2) - n0);
+            st = stage_issue(nz_h + 4ull * n0, nlen, lane);
         }
         __builtin_amdgcn_wave_barrier();
         {
             const h16x2* cp[G];
 #pragma unroll
             for (int h = 0; h < G; h++) cp[h] = qw + h * chead + c * (kChunkTiles / 2);
+            #ifdef MUSTAFAR_PROBE_HOTMETA
+            const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr);   // the fixed offsets of g_hot_idx stay inside the window
+#else
             const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
+#endif
             if constexpr (MF && G == 4) {
                 if (c == 0)      chunk32_mfma<0>(adj, bmp_t, idx_t, ctab_lane, accv);
                 else if (c == 1) chunk32_mfma<64>(adj, bmp_t + kChunkTiles, idx_t + kChunkTiles, ctab_lane, accv);
@@ -495,7 +544,7 @@ __device__ __forceinline__ void key_tokblk(unsigned char* smem, uint32_t lds_off
         }
         __builtin_amdgcn_wave_barrier();
         if (c < CB + CN - 1) {
-            stage_commit(lds, st, lane);
+            stage_commit(lds, st, lane, nlen);
             i0 = n0;
         }
     }
@@ -665,7 +714,7 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     int ldc, WinArgs wa, int64_t bmp_stride, int64_t idx_stride)
 {   // ldc: row stride of `out` in halfs (T for the reference layout); bmp_stride / idx_stride: elements between the heads'
     // rows of `bmp` / `idx` (0 = the reference's contiguous layout, 2T and 2T + 1; larger for an arena with spare capacity)
-    constexpr int kTabBytes = (MF && G == 4) ? 4 * kD * 2 : 0;   // MFMA engine: q rows of the 4 heads
+    constexpr int kTabBytes = (MF && G == 4) ? 4 * kKeyTabStride : 0;   // MFMA engine: q rows of the 4 heads
     __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
     MUSTAFAR_TRACE_BEGIN(1);
     const int lane = threadIdx.x & 63;
@@ -699,6 +748,9 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
     if (N > 1)
         rows |= pad_row_mask<G>(q, kD, bh0, N, 0, kD, reinterpret_cast<uint32_t*>(smem));
 
+    // One wave per token block (or two).  A grid capped at a few resident rounds with the waves looping over their
+    // blocks was measured too (round 2, both engines, caps 1024-4096 workgroups): 3-17 % slower at c5, no gain at c3 --
+    // what a one-block wave pays is the memory latency of its start-up chain, which a looping wave pays per block as well.
     const int tok0 = blockIdx.x * kTbPerWg * 64;
     const int ntok = min(kTbPerWg * 64, T - tok0);
     uint32_t ctab_lane = 0;
@@ -708,10 +760,10 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
                 unsigned char* tab = smem + kWaves * kStageBytes;
                 __syncthreads();
                 if (threadIdx.x < 64)
-                    reinterpret_cast<uint4*>(tab)[threadIdx.x] =
+                    *reinterpret_cast<uint4*>(tab + (threadIdx.x >> 4) * kKeyTabStride + (threadIdx.x & 15) * 16) =
                         *reinterpret_cast<const uint4*>(q + ((int64_t)(bh0 + (threadIdx.x >> 4)) * N + n) * kD + (threadIdx.x & 15) * 8);
                 __syncthreads();
-                ctab_lane = (uint32_t)reinterpret_cast<uintptr_t>(tab) + (lane & 3) * (kD * 2);
+                ctab_lane = (uint32_t)reinterpret_cast<uintptr_t>(tab) + (lane & 3) * kKeyTabStride;
             }
         }
         if ((rows >> n) & 1u) {
@@ -721,6 +773,9 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
             const h16x2* qw = reinterpret_cast<const h16x2*>(q + ((int64_t)bh0 * N + n) * kD);
             if (tb < ntb) {
                 if constexpr (SPLIT == 1) {
+#ifdef MUSTAFAR_PROBE_REPEAT   // timing-only build: every wave processes its token block MUSTAFAR_PROBE_REPEAT times (warm-cache cost per block)
+                    for (int rep = 0; rep < MUSTAFAR_PROBE_REPEAT; rep++)
+#endif
                     key_tokblk<G, MF, 0, 4>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc, ctab_lane);
                 } else {
                     if (part == 0) key_tokblk<G, MF, 0, 2>(smem, wave * kStageBytes, bmp_t, idx_t, nz_h, qw, chead, lane, acc, ctab_lane);
@@ -772,7 +827,7 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
     if (tb_first >= tb_end) return;
     unsigned char* lds = smem + lds_off;
     const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
-    // MFMA engine: per-wave coefficient table [4 heads][64 tokens] of the current token block (512 B), filled by
+    // MFMA engine: per-wave coefficient table [4 heads][64 tokens] of the current token block (4 x kValTabStride B), filled by
     // lanes 0..31 (16 B each) one token block ahead; lane l reads the row of head l % 4.
     f32x4 accv0 = {0.f, 0.f, 0.f, 0.f}, accv1 = {0.f, 0.f, 0.f, 0.f};
     uint32_t ctab_lane = 0;
@@ -782,16 +837,17 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
         return *reinterpret_cast<const uint4*>(src);
     };
     if constexpr (MF && G == 4) {
-        ctab_lane = (uint32_t)reinterpret_cast<uintptr_t>(ptab) + (lane & 3) * 128;
+        ctab_lane = (uint32_t)reinterpret_cast<uintptr_t>(ptab) + (lane & 3) * kValTabStride;
         ptv = ptab_load(tb_first);
-        if (lane < 32) reinterpret_cast<uint4*>(ptab)[lane] = ptv;
+        if (lane < 32) *reinterpret_cast<uint4*>(ptab + (lane >> 3) * kValTabStride + (lane & 7) * 16) = ptv;
     }
     uint32_t pf = prefetch_meta<G>(bmp_h + (int64_t)tb_first * kTilesPerTb, idx_h + (int64_t)tb_first * kTilesPerTb,
                                    pw + (uint32_t)tb_first * 32u, chead, lane);
     uint32_t bnd = bnd_load(idx_h + (int64_t)tb_first * kTilesPerTb, lane);
     uint32_t i0 = bnd_get(bnd, CB);
-    Stage st = stage_issue(nz_h + 4ull * i0, 4u * (bnd_get(bnd, CB + 1) - i0), lane);
-    stage_commit(lds, st, lane);
+    const uint32_t len0 = 4u * (bnd_get(bnd, CB + 1) - i0);
+    Stage st = stage_issue(nz_h + 4ull * i0, len0, lane);
+    stage_commit(lds, st, lane, len0);
     for (int tb = tb_first; tb < tb_end; tb += STRIDE) {
         const uint64_t* bmp_t = bmp_h + (int64_t)tb * kTilesPerTb;
         const uint32_t* idx_t = idx_h + (int64_t)tb * kTilesPerTb;
@@ -805,20 +861,25 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
         if constexpr (MF && G == 4) ptv = ptab_load(tbn);
 #pragma unroll
         for (int c = CB; c < CB + CN; c++) {
-            uint32_t n0 = 0;
+            uint32_t n0 = 0, nlen = 0;
             const bool last = c == CB + CN - 1;
             const bool has_next = !last || more;
             if (has_next) {
                 n0 = !last ? bnd_get(bnd, c + 1) : bnd_get(bnd_next, CB);
                 const uint32_t n1 = !last ? bnd_get(bnd, c + 2) : bnd_get(bnd_next, CB + 1);
-                st = stage_issue(nz_h + 4ull * n0, 4u * (n1 - n0), lane);
+                nlen = 4u * (n1 - n0);
+                st = stage_issue(nz_h + 4ull * n0, nlen, lane);
             }
             __builtin_amdgcn_wave_barrier();
             // chunk c: channel half = c >> 1, tokens (c & 1) * 32 .. +31 of the block
             const h16x2* cp[G];
 #pragma unroll
             for (int h = 0; h < G; h++) cp[h] = pw + h * chead + ((uint32_t)tb * 64u + (c & 1) * 32u) / 2u;
+            #ifdef MUSTAFAR_PROBE_HOTMETA
+            const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr);   // the fixed offsets of g_hot_idx stay inside the window
+#else
             const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
+#endif
             if constexpr (MF && G == 4) {
                 if (c == 0)      chunk32_mfma<0>(adj, bmp_t, idx_t, ctab_lane, accv0);
                 else if (c == 1) chunk32_mfma<64>(adj, bmp_t + kChunkTiles, idx_t + kChunkTiles, ctab_lane, accv0);
@@ -830,12 +891,12 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
             }
             __builtin_amdgcn_wave_barrier();
             if (has_next) {
-                stage_commit(lds, st, lane);
+                stage_commit(lds, st, lane, nlen);
                 i0 = n0;
             }
         }
         if constexpr (MF && G == 4) {
-            if (more && lane < 32) reinterpret_cast<uint4*>(ptab)[lane] = ptv;   // this block's table is dead now
+            if (more && lane < 32) *reinterpret_cast<uint4*>(ptab + (lane >> 3) * kValTabStride + (lane & 7) * 16) = ptv;   // this block's table is dead now
             __builtin_amdgcn_wave_barrier();
         }
         bnd = bnd_next;
@@ -864,7 +925,7 @@ __global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
     uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb, WinArgs wa,
     int64_t bmp_stride, int64_t idx_stride)
 {   // bmp_stride / idx_stride: as in key_spmv_kernel;  ldb: row stride of `p` in halfs (T for the reference layout; must be even, % 8 == 0 for the MFMA engine)
-    constexpr int kTabBytes = (MF && G == 4) ? NW * 512 : 0;
+    constexpr int kTabBytes = (MF && G == 4) ? NW * 4 * kValTabStride : 0;
     constexpr int kStride = NW / SPLIT;   // token blocks in flight per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char smem[NW * kStageBytes + kTabBytes];
     MUSTAFAR_TRACE_BEGIN(2);
@@ -912,7 +973,7 @@ __global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
         for (int h = 0; h < G; h++) acc0[h] = acc1[h] = 0.f;
         if (live) {
             const h16x2* pw = reinterpret_cast<const h16x2*>(p + ((int64_t)bh0 * N + n) * ldb);
-            unsigned char* ptab = smem + NW * kStageBytes + wave * 512;
+            unsigned char* ptab = smem + NW * kStageBytes + wave * (4 * kValTabStride);
             const int tb_first = tb0 + wave / SPLIT;
             if constexpr (SPLIT == 1) {
                 value_tokblks<G, MF, 0, 4, kStride>(smem, wave * kStageBytes, bmp_h, idx_h, nz_h, pw, chead, tb_first, tb_end, lane, acc0, acc1, ptab);
@@ -1011,9 +1072,28 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh)
 // The quotient is formed as a product with 1/sqrt(d): at most 1 fp32 ulp away before the fp16 rounding.
 __device__ __forceinline__ float scaled(h16 a, float inv_sqrt_d) { return (float)(h16)((float)a * inv_sqrt_d); }
 
+// Additive attention mask of the reference hook (llama_mustafar_kernel.py:293-301): `attn_weights + attention_mask` is
+// an fp16 addition (both operands fp16; the fp32 sum of two fp16 values followed by one rounding is that addition), then
+// `torch.max(., finfo(fp16).min)` lifts an overflow to -inf back to -65504.  `m` is the mask value of the column.
+__device__ __forceinline__ float masked(float x, h16 m)
+{
+    return fmaxf((float)(h16)(x + (float)m), -65504.f);
+}
+// fp16 [rows, >= kv_len] mask, `stride` halfs between rows; score row bh uses mask row bh / heads (heads = q heads per
+// batch entry: the reference mask is [bsz, 1, 1, kv_len], broadcast over heads).  ptr == nullptr: no mask.
+struct MaskArg {
+    const h16* ptr;
+    int64_t stride;
+    int heads;
+};
+struct __attribute__((packed, aligned(2))) Half8U {   // 8 halfs at 2-byte alignment (kv_len is arbitrary): one global_load_dwordx4
+    h16 h[8];
+};
+
+template <bool MASK>
 __global__ __launch_bounds__(kGlueThreads) void window_softmax_kernel(
     const h16* __restrict__ q, h16* __restrict__ k_win, const h16* __restrict__ k_new, h16* __restrict__ scores,
-    int T, int ld, int w_len, int w_cap, int groups, float inv_sqrt_d, const int* __restrict__ w_extra)
+    int T, int ld, int w_len, int w_cap, int groups, float inv_sqrt_d, const int* __restrict__ w_extra, MaskArg mask)
 {
     __shared__ float sh[kGlueWaves];
     __shared__ h16 wsc[kMaxWindow];
@@ -1067,15 +1147,30 @@ __global__ __launch_bounds__(kGlueThreads) void window_softmax_kernel(
     }
     __syncthreads();
 
-    // (3) fp32 softmax over x_i = fp16(score_i / sqrt(d))  (:284, :304)
+    // (3) fp32 softmax over x_i = fp16(score_i / sqrt(d)) (+ mask)  (:284, :293-304).  xs() is the softmax input of
+    // element j of register slot i; with a mask the row registers are rewritten once with the masked values
+    const h16* mrow = MASK ? mask.ptr + (int64_t)(bh / mask.heads) * mask.stride : nullptr;
+    if constexpr (MASK) {
+#pragma unroll
+        for (int i = 0; i < kMaxRowVecs; i++) {
+            const int v = tid + i * kGlueThreads;
+            if (v < nvec) {
+                const Half8U mv = *reinterpret_cast<const Half8U*>(mrow + 8 * (int64_t)v);
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[i].h[j] = (h16)masked(scaled(x[i].h[j], inv_sqrt_d), mv.h[j]);
+            }
+        }
+        for (int w = tid; w < w_len; w += kGlueThreads) wsc[w] = (h16)masked(scaled(wsc[w], inv_sqrt_d), mrow[T + w]);
+    }
+    auto xs = [&](h16 a) -> float { return MASK ? (float)a : scaled(a, inv_sqrt_d); };
     float m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < kMaxRowVecs; i++)
         if (i * kGlueThreads < nvec) {   // workgroup-uniform: skip register slots beyond the row
 #pragma unroll
-            for (int j = 0; j < 8; j++) m = fmaxf(m, scaled(x[i].h[j], inv_sqrt_d));
+            for (int j = 0; j < 8; j++) m = fmaxf(m, xs(x[i].h[j]));
         }
-    for (int w = tid; w < w_len; w += kGlueThreads) m = fmaxf(m, scaled(wsc[w], inv_sqrt_d));
+    for (int w = tid; w < w_len; w += kGlueThreads) m = fmaxf(m, xs(wsc[w]));
     m = block_reduce<kGlueWaves>(m, true, sh);
     float l = 0.f;
     float e[kMaxRowVecs][8];
@@ -1084,11 +1179,11 @@ __global__ __launch_bounds__(kGlueThreads) void window_softmax_kernel(
         if (i * kGlueThreads < nvec) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                e[i][j] = __expf(scaled(x[i].h[j], inv_sqrt_d) - m);   // exp(-inf) = 0 for the padding lanes
+                e[i][j] = __expf(xs(x[i].h[j]) - m);   // exp(-inf) = 0 for the padding lanes
                 l += e[i][j];
             }
         }
-    for (int w = tid; w < w_len; w += kGlueThreads) l += __expf(scaled(wsc[w], inv_sqrt_d) - m);
+    for (int w = tid; w < w_len; w += kGlueThreads) l += __expf(xs(wsc[w]) - m);
     l = block_reduce<kGlueWaves>(l, false, sh);
     const float inv = 1.f / l;
 #pragma unroll
@@ -1101,46 +1196,54 @@ __global__ __launch_bounds__(kGlueThreads) void window_softmax_kernel(
             reinterpret_cast<uint4*>(row)[v] = o.u;
         }
     }
-    for (int w = tid; w < w_len; w += kGlueThreads) row[T + w] = (h16)(__expf(scaled(wsc[w], inv_sqrt_d) - m) * inv);
+    for (int w = tid; w < w_len; w += kGlueThreads) row[T + w] = (h16)(__expf(xs(wsc[w]) - m) * inv);
 }
 
 // Rows longer than the register form holds (T > 32768): the same softmax as three passes over the row in global memory
 // (max, denominator, write); the window scores must already be in the row (T > 0: the key launch's window workgroups).
+template <bool MASK>
 __global__ __launch_bounds__(kGlueThreads) void long_softmax_kernel(h16* __restrict__ scores, int T, int ld, int w_len, int w_cap,
-                                                                    float inv_sqrt_d, const int* __restrict__ w_extra)
+                                                                    float inv_sqrt_d, const int* __restrict__ w_extra, MaskArg mask)
 {
     __shared__ float sh[kGlueWaves];
     if (w_extra) w_len = min(w_len + *w_extra, w_cap);
     const int tid = threadIdx.x;
     h16* row = scores + (int64_t)blockIdx.x * ld;
+    const h16* mrow = MASK ? mask.ptr + (int64_t)((int)blockIdx.x / mask.heads) * mask.stride : nullptr;
     const int nvec = T / 8, n = T + w_len;
+    // softmax input of column c holding raw score a (:284, :293-301)
+    auto xs = [&](h16 a, h16 mk) -> float { return MASK ? masked(scaled(a, inv_sqrt_d), mk) : scaled(a, inv_sqrt_d); };
+    auto mvec = [&](int v) -> Half8U { return MASK ? *reinterpret_cast<const Half8U*>(mrow + 8 * (int64_t)v) : Half8U{}; };
     float m = -INFINITY;
     for (int v = tid; v < nvec; v += kGlueThreads) {
         Vec8 x;
         x.u = reinterpret_cast<const uint4*>(row)[v];
+        const Half8U mv = mvec(v);
 #pragma unroll
-        for (int j = 0; j < 8; j++) m = fmaxf(m, scaled(x.h[j], inv_sqrt_d));
+        for (int j = 0; j < 8; j++) m = fmaxf(m, xs(x.h[j], mv.h[j]));
     }
-    for (int i = T + tid; i < n; i += kGlueThreads) m = fmaxf(m, scaled(row[i], inv_sqrt_d));
+    for (int i = T + tid; i < n; i += kGlueThreads) m = fmaxf(m, xs(row[i], MASK ? mrow[i] : (h16)0));
     m = block_reduce<kGlueWaves>(m, true, sh);
     float l = 0.f;
     for (int v = tid; v < nvec; v += kGlueThreads) {
         Vec8 x;
         x.u = reinterpret_cast<const uint4*>(row)[v];
+        const Half8U mv = mvec(v);
 #pragma unroll
-        for (int j = 0; j < 8; j++) l += __expf(scaled(x.h[j], inv_sqrt_d) - m);
+        for (int j = 0; j < 8; j++) l += __expf(xs(x.h[j], mv.h[j]) - m);
     }
-    for (int i = T + tid; i < n; i += kGlueThreads) l += __expf(scaled(row[i], inv_sqrt_d) - m);
+    for (int i = T + tid; i < n; i += kGlueThreads) l += __expf(xs(row[i], MASK ? mrow[i] : (h16)0) - m);
     l = block_reduce<kGlueWaves>(l, false, sh);
     const float inv = 1.f / l;
     for (int v = tid; v < nvec; v += kGlueThreads) {
         Vec8 x, o;
         x.u = reinterpret_cast<const uint4*>(row)[v];
+        const Half8U mv = mvec(v);
 #pragma unroll
-        for (int j = 0; j < 8; j++) o.h[j] = (h16)(__expf(scaled(x.h[j], inv_sqrt_d) - m) * inv);
+        for (int j = 0; j < 8; j++) o.h[j] = (h16)(__expf(xs(x.h[j], mv.h[j]) - m) * inv);
         reinterpret_cast<uint4*>(row)[v] = o.u;
     }
-    for (int i = T + tid; i < n; i += kGlueThreads) row[i] = (h16)(__expf(scaled(row[i], inv_sqrt_d) - m) * inv);
+    for (int i = T + tid; i < n; i += kGlueThreads) row[i] = (h16)(__expf(xs(row[i], MASK ? mrow[i] : (h16)0) - m) * inv);
 }
 
 __global__ void counter_add_kernel(int* ctr, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += delta; }
@@ -1352,7 +1455,7 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
 
 extern "C" {
 
-int mustafar_abi_version(void) { return 100; }
+int mustafar_abi_version(void) { return 101; }
 
 int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
                    const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,
@@ -1442,9 +1545,12 @@ namespace {
 int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar_cache_view& vc, const void* q, void* k_window,
                      void* v_window, const void* k_new, const void* v_new, int window_len, int window_capacity, void* scores,
                      int ld_scores, void* out, void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups,
-                     float sqrt_d, const int32_t* window_len_extra)
+                     float sqrt_d, const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
+                     int heads_per_mask_row)
 {
     const int groups = num_key_value_groups;
+    if (attention_mask && (heads_per_mask_row < 1 || Batch_Size % heads_per_mask_row || mask_row_stride < 0)) return MUSTAFAR_EINVAL;
+    const MaskArg mask{static_cast<const h16*>(attention_mask), mask_row_stride, heads_per_mask_row > 0 ? heads_per_mask_row : 1};
     if (T < 0 || (T & 63) || groups < 1 || Batch_Size < 1 || Batch_Size % groups || window_len < 1 ||
         window_len > window_capacity || window_capacity > kMaxWindow ||
         ld_scores < T + (window_len_extra ? window_capacity : window_len) || (ld_scores & 7) || Split_K < 1 || !(sqrt_d > 0.f))
@@ -1476,13 +1582,16 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                    prof ? g_prof.ev[4 * g_prof.n] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr, kc.bmp_head_stride,
                    kc.idx_head_stride);
     }
-    if (long_rows)
-        long_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(sc, T, ld_scores, window_len, window_capacity,
-                                                                 (float)(1.0 / (double)sqrt_d), window_len_extra);
-    else
-        window_softmax_kernel<<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride_k ? nullptr : kwin, ride_k ? nullptr : knew, sc,
-                                                                   T, ld_scores, window_len, window_capacity, groups,
-                                                                   (float)(1.0 / (double)sqrt_d), window_len_extra);
+    const float inv_sqrt_d = (float)(1.0 / (double)sqrt_d);
+    if (long_rows) {
+        if (mask.ptr) long_softmax_kernel<true><<<Batch_Size, kGlueThreads, 0, st>>>(sc, T, ld_scores, window_len, window_capacity, inv_sqrt_d, window_len_extra, mask);
+        else          long_softmax_kernel<false><<<Batch_Size, kGlueThreads, 0, st>>>(sc, T, ld_scores, window_len, window_capacity, inv_sqrt_d, window_len_extra, mask);
+    } else {
+        if (mask.ptr) window_softmax_kernel<true><<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride_k ? nullptr : kwin, ride_k ? nullptr : knew, sc, T, ld_scores, window_len,
+                                                                                     window_capacity, groups, inv_sqrt_d, window_len_extra, mask);
+        else          window_softmax_kernel<false><<<Batch_Size, kGlueThreads, 0, st>>>(qh, ride_k ? nullptr : kwin, ride_k ? nullptr : knew, sc, T, ld_scores, window_len,
+                                                                                      window_capacity, groups, inv_sqrt_d, window_len_extra, mask);
+    }
     float* ws = static_cast<float*>(workspace);
     if (T > 0) {
         const int ntb = T / 64;
@@ -1513,27 +1622,30 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
                               const uint32_t* v_nz_offset, const void* q, void* k_window, void* v_window, const void* k_new,
                               const void* v_new, int window_len, int window_capacity, void* scores, int ld_scores, void* out,
                               void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
-                              const int32_t* window_len_extra)
+                              const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
+                              int heads_per_mask_row)
 {
     const mustafar_cache_view kc{const_cast<uint64_t*>(k_bmp), const_cast<void*>(k_nz), const_cast<uint32_t*>(k_idx),
                                  const_cast<uint32_t*>(k_nz_offset), 0, 0};
     const mustafar_cache_view vc{const_cast<uint64_t*>(v_bmp), const_cast<void*>(v_nz), const_cast<uint32_t*>(v_idx),
                                  const_cast<uint32_t*>(v_nz_offset), 0, 0};
     return decode_attention(stream, kc, vc, q, k_window, v_window, k_new, v_new, window_len, window_capacity, scores, ld_scores, out,
-                            workspace, Split_K, T, Batch_Size, num_key_value_groups, sqrt_d, window_len_extra);
+                            workspace, Split_K, T, Batch_Size, num_key_value_groups, sqrt_d, window_len_extra, attention_mask,
+                            mask_row_stride, heads_per_mask_row);
 }
 
 int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_cache, const mustafar_cache_view* v_cache,
                                    const void* q, void* k_window, void* v_window, const void* k_new, const void* v_new,
                                    int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
                                    int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
-                                   const int32_t* window_len_extra)
+                                   const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
+                                   int heads_per_mask_row)
 {
     const mustafar_cache_view none{nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (T > 0 && (!k_cache || !v_cache)) return MUSTAFAR_EINVAL;
     return decode_attention(stream, k_cache ? *k_cache : none, v_cache ? *v_cache : none, q, k_window, v_window, k_new, v_new,
                             window_len, window_capacity, scores, ld_scores, out, workspace, Split_K, T, Batch_Size,
-                            num_key_value_groups, sqrt_d, window_len_extra);
+                            num_key_value_groups, sqrt_d, window_len_extra, attention_mask, mask_row_stride, heads_per_mask_row);
 }
 
 int mustafar_profile_begin(int max_records)

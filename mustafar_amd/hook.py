@@ -216,8 +216,14 @@ class MustafarAttention:
             self._ws_fused = torch.empty(max(ws_bytes, 1 << 20), dtype=torch.uint8, device=device)
         return self._scores, self._ws_fused
 
-    def decode_fused(self, query_states, key_states, value_states, past, step_counter: Optional[torch.Tensor] = None):
+    def decode_fused(self, query_states, key_states, value_states, past, step_counter: Optional[torch.Tensor] = None,
+                     attention_mask: Optional[torch.Tensor] = None):
         """Same contract as decode() with api="native"; windows are `Window` objects appended in place.
+
+        `attention_mask` is the hook's additive mask [bsz, 1, 1, kv_seq_len] (model :293-301), applied inside the softmax
+        kernel exactly as the model does (fp16 add, clamp at finfo.min).  Under graph replay (`step_counter`) pass a
+        buffer whose rows are at least `compressed_length + window capacity` long: the kernels read the first
+        `kv_seq_len` columns of each row, whatever the step.
 
         `step_counter` (int32 device tensor, optional) is added to the window length inside the kernels, so that a
         captured graph of this call can be replayed for consecutive steps (advance it with mustafar_counter_add once
@@ -243,11 +249,22 @@ class MustafarAttention:
         vn = value_states if value_states.is_contiguous() else value_states.contiguous()
         if k_w.cap != v_w.cap:
             raise RuntimeError("key/value windows must have the same capacity")
+        mask_ptr, mask_stride = None, 0
+        if attention_mask is not None:
+            need = C + w_len if step_counter is None else C + 1   # (a replayed graph reads more columns as the window grows)
+            if attention_mask.dim() != 4 or attention_mask.shape[:3] != (bsz, 1, q_len) or attention_mask.shape[3] < need or \
+                    (step_counter is None and attention_mask.shape[3] != kv_seq_len):
+                raise ValueError(f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {tuple(attention_mask.size())}")   # :294-297
+            if attention_mask.dtype != torch.float16 or attention_mask.device != dev:
+                raise RuntimeError("attention_mask must be a float16 tensor on the device of the query")
+            if attention_mask.stride(3) != 1:
+                attention_mask = attention_mask.contiguous()
+            mask_ptr, mask_stride = attention_mask.data_ptr(), attention_mask.stride(0) if bsz > 1 else attention_mask.shape[3]
         p = lambda t: t.data_ptr() if t is not None else None
         use_arena = isinstance(k_c, CompressedArena)
         tail = (q.data_ptr(), k_w.buf.data_ptr(), v_w.buf.data_ptr(), kn.data_ptr(), vn.data_ptr(), w_len, k_w.cap,
                 scores.data_ptr(), ld, out.data_ptr(), ws.data_ptr(), split, C, BH, groups, math.sqrt(D),
-                step_counter.data_ptr() if step_counter is not None else None)
+                step_counter.data_ptr() if step_counter is not None else None, mask_ptr, mask_stride, self.num_heads)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             if use_arena:
@@ -285,8 +302,8 @@ class MustafarAttention:
     def decode(self, query_states, key_states, value_states, past, attention_mask=None):
         """q [B,Hq,1,D], new k/v [B,Hkv,1,D] -> (attn_output [B,Hq,1,D], past)."""
         cfg = self.cfg
-        if cfg.api == "fused" and attention_mask is None:
-            return self.decode_fused(query_states, key_states, value_states, past)
+        if cfg.api == "fused":
+            return self.decode_fused(query_states, key_states, value_states, past, attention_mask=attention_mask)
         if isinstance(past[1], Window):   # a fused cache handed to the unfused path
             past = (past[0], past[1].view(), past[2], past[3].view(), past[4], past[5])
         if isinstance(past[0], CompressedArena):

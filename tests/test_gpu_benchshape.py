@@ -1,0 +1,182 @@
+"""GPU: the path bench.py TIMES, at the shapes it times it -- fused decode over the arena cache, eagerly and as a
+replayed hipGraph, at the BASELINE configs c2-c5 (one layer each; bench.py runs 32 of them).  At these sizes the launches
+carry what no small test has: 256 rows, Split_K ~ 32, window workgroups riding both SpMV grids, both key launch forms.
+
+Checks, per config:
+  * fused (eager) == dense fp32 attention over K/V pruned by the prune rule (the GPU prune kernel, itself held bit-exact
+    to the reference's dh_prune_* fixtures and, here, to the CPU oracle on one head at full T); fp16 tolerance
+    (rtol 4e-3, atol 2e-3: the hook tests' bar)
+  * fused == the two reference entry points with PyTorch glue (api="native") within 2 fp16 ulp of the output scale
+  * the same step replayed from a captured graph >= 3 times while the window grows == dense
+  * c3, c5: eager steps across the 256-token compression trigger (32nd decode step) == dense, arena append included
+  * c3/c4/c5: the C oracle's key and value SpMV on ONE kv-head at full T against the HIP result (fp16_bound, tests/util.py)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.util import fp16_bound
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CASES = {  # BASELINE.json configs[1..4]: (Hq, Hkv, sparsity, L, batch)
+    "c2": (32, 32, 0.7, 4096, 1),
+    "c3": (32, 8, 0.7, 8192, 8),
+    "c4": (32, 8, 0.8, 32768, 4),
+    "c5": (32, 8, 0.7, 16384, 16),
+}
+
+
+class DenseRef:
+    """Dense attention over pruned-but-dense K/V (the relation between the reference's kernel model and its dense model,
+    llama_mustafar_Kt_Mag_Vt_Mag.py:873, :963, :974), kept on the GPU in fp16 and evaluated in fp32 per kv-head group."""
+
+    def __init__(self, K, V, C, s, groups):
+        from mustafar_amd import compression
+        self.prune = lambda x: compression.prune_magnitude(x.contiguous(), s)
+        self.K, self.V, self.C, self.groups = K.clone(), V.clone(), C, groups
+        self.K[:, :, :C] = self.prune(K[:, :, :C])
+        self.V[:, :, :C] = self.prune(V[:, :, :C])
+
+    def append(self, k, v):
+        self.K, self.V = torch.cat([self.K, k], 2), torch.cat([self.V, v], 2)
+
+    def compress_next_256(self):
+        C = self.C
+        self.K[:, :, C:C + 256] = self.prune(self.K[:, :, C:C + 256])
+        self.V[:, :, C:C + 256] = self.prune(self.V[:, :, C:C + 256])
+        self.C += 256
+
+    def __call__(self, q):
+        B, Hq, _, D = q.shape
+        Hkv = self.K.shape[1]
+        out = torch.empty((B, Hq, 1, D), dtype=torch.float32, device=q.device)
+        qg = q.view(B, Hkv, self.groups, D).float()
+        for b in range(B):     # one batch entry at a time bounds the fp32 temporaries (c4: 32 k tokens)
+            s = torch.einsum("hgd,htd->hgt", qg[b], self.K[b].float()) / math.sqrt(D)
+            out[b] = torch.einsum("hgt,htd->hgd", torch.softmax(s, -1), self.V[b].float()).reshape(Hq, 1, D)
+        return out
+
+
+def _setup(name, arena=True):
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    Hq, Hkv, s, L, batch = CASES[name]
+    torch.manual_seed(42)
+    cfg = MustafarConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, k_sparsity=s, v_sparsity=s, residual_length=32,
+                         api="fused", arena=arena)
+    attn = MustafarAttention(cfg)
+    K = torch.randn(batch, Hkv, L, 128, device=DEV).half()
+    V = torch.randn(batch, Hkv, L, 128, device=DEV).half()
+    T = ((L - 32) // 256) * 256
+    past = attn.to_fused(attn.build_cache(K, V))
+    assert past[4] == T
+    ref = DenseRef(K, V, T, s, Hq // Hkv)
+    return attn, cfg, past, ref, (Hq, Hkv, batch, T)
+
+
+def _new(batch, Hq, Hkv):
+    return (torch.randn(batch, Hq, 1, 128, device=DEV).half(), torch.randn(batch, Hkv, 1, 128, device=DEV).half(),
+            torch.randn(batch, Hkv, 1, 128, device=DEV).half())
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+def test_fused_arena_eager_and_graph_at_bench_shape(name):
+    from mustafar_amd import _lib
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    attn, cfg, past, ref, (Hq, Hkv, batch, T) = _setup(name)
+    from mustafar_amd.cache import CompressedArena
+    assert isinstance(past[0], CompressedArena) and isinstance(past[2], CompressedArena)
+    # the same cache in the reference layout for the unfused call sequence
+    native = MustafarAttention(MustafarConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, k_sparsity=cfg.k_sparsity,
+                                              v_sparsity=cfg.v_sparsity, residual_length=32, api="native"))
+    past_n = (past[0].to_reference(), past[1].view().clone(), past[2].to_reference(), past[3].view().clone(), past[4], past[5])
+    # ---- eager, 3 steps
+    for _ in range(3):
+        q, k, v = _new(batch, Hq, Hkv)
+        ref.append(k, v)
+        out, past = attn.decode(q, k, v, past)
+        out_n, past_n = native.decode(q, k, v, past_n)
+        want = ref(q)
+        torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
+        scale = float(want.abs().max())
+        assert float((out.float() - out_n.float()).abs().max()) <= 2 * 2.0 ** -11 * max(scale, 2.0 ** -6) + 1e-4, \
+            "fused and unfused call sequences disagree beyond 2 ulp of the output scale"
+    del past_n
+    # ---- the same call captured once and replayed (bench.py's timed form)
+    q, k, v = (torch.zeros_like(t) for t in _new(batch, Hq, Hkv))
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib = _lib.load()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out, _ = attn.decode_fused(q, k, v, past, step_counter=counter)
+        _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream().cuda_stream, counter.data_ptr(), 1), "counter")
+    for _ in range(4):
+        qn, kn, vn = _new(batch, Hq, Hkv)
+        q.copy_(qn); k.copy_(kn); v.copy_(vn)
+        ref.append(kn, vn)
+        g.replay()
+        torch.testing.assert_close(out.float(), ref(qn), rtol=4e-3, atol=2e-3)
+    past = attn.advance(past, 4)
+    assert past[1].len == past[5] - T
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["c3", "c5"])
+def test_fused_arena_across_the_compression_trigger_at_bench_shape(name):
+    """L = 8192 / 16384 leave a 256-token window: the 32nd decode step fires the trigger (model :324): prune + in-place
+    arena append of 256 tokens per head, then decode continues over T + 256 compressed tokens."""
+    attn, cfg, past, ref, (Hq, Hkv, batch, T) = _setup(name)
+    fired = 0
+    for step in range(35):
+        q, k, v = _new(batch, Hq, Hkv)
+        ref.append(k, v)
+        C_before = past[4]
+        out, past = attn.decode(q, k, v, past)
+        if step in (0, 30, 31, 32, 34):
+            torch.testing.assert_close(out.float(), ref(q), rtol=4e-3, atol=2e-3)
+        if past[4] != C_before:
+            fired += 1
+            ref.compress_next_256()
+            assert step == 31 and past[4] == T + 256 and past[0].tokens == T + 256 and past[1].len == 32
+    assert fired == 1
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["c3", "c4", "c5"])
+def test_one_head_at_full_length_against_the_c_oracle(name):
+    """The CPU oracle finishes one kv-head at full T in seconds: prune, compress and both SpMVs of that head, HIP vs C."""
+    from mustafar_amd import compression, mustafar_package as mp
+    Hq, Hkv, s, L, batch = CASES[name]
+    T, groups, D = ((L - 32) // 256) * 256, Hq // Hkv, 128
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((1, T, D)).astype(np.float16)
+    xg = torch.from_numpy(x).to(DEV)
+    want_pruned = orc.prune_magnitude(x, s)
+    pruned = compression.prune_magnitude(xg, s)
+    assert np.array_equal(pruned.cpu().numpy().view(np.uint16), want_pruned.view(np.uint16))
+    q = rng.standard_normal((groups, 1, D)).astype(np.float16)
+    p = torch.softmax(torch.from_numpy(rng.standard_normal((groups, 1, T)).astype(np.float32) * 2), -1).half().numpy()
+    dense = want_pruned[0].astype(np.float64)
+    for which in ("key", "value"):
+        conv_g = compression.convert_key_batched if which == "key" else compression.convert_value_batched
+        conv_o = orc.convert_key_batched if which == "key" else orc.convert_value_batched
+        bmp, idx, nzs = conv_g(pruned)
+        obmp, oidx, onzs = conv_o(want_pruned)
+        assert np.array_equal(bmp.cpu().numpy(), obmp) and np.array_equal(idx.cpu().numpy(), oidx)
+        assert np.array_equal(torch.cat(nzs).cpu().numpy().view(np.uint16), np.concatenate(onzs).view(np.uint16))
+        off = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ooff = orc.nz_offset_from_idx(oidx)
+        if which == "key":
+            got = mp.mustafar_key_formulation(bmp, torch.cat(nzs), idx, off, torch.from_numpy(q).to(DEV), T, D, groups, groups)
+            _, ref64 = orc.key_spmv(obmp, np.concatenate(onzs), oidx, ooff, q, T, D, groups, groups)
+            sumabs = np.stack([np.abs(dense) @ np.abs(q[b, 0].astype(np.float64)) for b in range(groups)])[:, None]
+        else:
+            ws = torch.zeros(1, dtype=torch.float16, device=DEV)
+            got = mp.mustafar_value_formulation(bmp, torch.cat(nzs), idx, off, torch.from_numpy(p).to(DEV), ws, D, T, groups, groups)
+            _, ref64 = orc.value_spmv(obmp, np.concatenate(onzs), oidx, ooff, p, D, T, groups, groups)
+            sumabs = np.stack([np.abs(p[b, 0].astype(np.float64)) @ np.abs(dense) for b in range(groups)])[:, None]
+        err = np.abs(got.float().cpu().numpy().astype(np.float64) - ref64)
+        assert (err <= fp16_bound(ref64, sumabs)).all(), f"{name} {which}: HIP SpMV outside the fp16 bound of the oracle's exact sum"

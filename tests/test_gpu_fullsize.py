@@ -1,6 +1,6 @@
 """GPU: the hot path at BASELINE.json's full sizes (one layer), checked through size-independent properties --
 the CPU oracle would take minutes here.  Geometries: c1 (Llama-2-7B, 50 %, L=1024, b1: the reference's CPU-runnable case), c2 (Llama-2-7B, L=4096, b1), c3 (Llama-3-8B GQA, L=8192, b8),
-c4 (L=32768, b4, 80 %).  Tolerances: integer invariants exact; SpMV vs a torch fp32 matmul over the pruned dense tensor
+c4 (L=32768, b4, 80 %), c5 (Mistral-7B geometry, L=16384, b16, 70 %).  Tolerances: integer invariants exact; SpMV vs a torch fp32 matmul over the pruned dense tensor
 within fp16 (rtol 3e-3, atol scaled by sqrt(K)); linearity within the same bound."""
 import math
 
@@ -10,7 +10,8 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-CASES = {"c1": (32, 32, 0.5, 1024, 1), "c2": (32, 32, 0.7, 4096, 1), "c3": (32, 8, 0.7, 8192, 8), "c4": (32, 8, 0.8, 32768, 4)}
+CASES = {"c1": (32, 32, 0.5, 1024, 1), "c2": (32, 32, 0.7, 4096, 1), "c3": (32, 8, 0.7, 8192, 8), "c4": (32, 8, 0.8, 32768, 4),
+         "c5": (32, 8, 0.7, 16384, 16)}
 
 
 def _popcount64(x: torch.Tensor) -> torch.Tensor:
@@ -26,7 +27,7 @@ def _popcount64(x: torch.Tensor) -> torch.Tensor:
     return cnt
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
 def test_full_size_invariants_and_spmv(name):
     from mustafar_amd import compression, mustafar_package as mp
     from mustafar_amd.hook import nz_offset_from_idxs

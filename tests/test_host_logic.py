@@ -35,7 +35,7 @@ def test_cabi_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for s in syms:
         assert hasattr(raw, s), f"{s} not exported"
-    assert L.mustafar_abi_version() >= 100
+    assert L.mustafar_abi_version() >= 101
     # pure host helpers (no device access)
     s = L.mustafar_value_pick_split_k(128, 1, 7936, 256, 4)
     assert 1 <= s <= 31
@@ -50,7 +50,7 @@ def test_cache_view_strides_are_validated_without_a_gpu():
     L = _lib.load()
     one = 8   # never dereferenced: validation fails first
     T = 128
-    ok_args = (one, one, one, None, None, 1, 64, one, T + 64, one, one, 1, T, 4, 1, ctypes.c_float(11.3), None)
+    ok_args = (one, one, one, None, None, 1, 64, one, T + 64, one, one, 1, T, 4, 1, ctypes.c_float(11.3), None, None, 0, 0)
     short = _lib.CacheView(one, one, one, one, 2 * T - 1, 0)
     good = _lib.CacheView(one, one, one, one, 2 * T, 2 * T + 1)
     assert L.mustafar_decode_attention_view(None, ctypes.byref(short), ctypes.byref(good), *ok_args) == 1
