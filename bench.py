@@ -12,16 +12,27 @@ Workloads: c2 Llama-2-7B 70% L=4096 b1 | c3 Llama-3-8B 70% L=8192 
 metric is quoted on) | c4 Llama-3-8B 80% L=32768 b4 | c5 Mistral-7B 70% L=16384 b16 | c1 plumbing.
 
 Multi-GPU: the path does not shard one sequence (north_star) -> independent replicas, one process per GPU,
-no data-path collective; `value` = units of all ranks / max-over-ranks time ("scaling": "weak").
+no data-path collective; `value` = units of all ranks / max-over-ranks time ("scaling": "weak").  Under
+torch.distributed.run the ranks come from the environment; a plain `python bench.py --gpus N` starts N fresh
+child processes itself (before this process touches the GPU).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects, plus:
+  self_check     the timed call sequence against the two reference entry points, every layer, before the timed region
+                 (a mismatch ends the run with a non-zero exit code and no line)
+  roofline_mfma  the same measurement on the opt-in matrix-pipe FMA engine
+  configs        c2 / c4 / c5 sub-results (N = 1 only)
+  tokens_per_sec_incl_trigger   >= 256 consecutive steps, the 256-token compression trigger included
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,6 +49,13 @@ CONFIGS = {  # name: (label, Hq, Hkv, sparsity, L, batch)
     "c5": ("Mistral-7B 70% L=16384 b16", 32, 8, 0.7, 16384, 16),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
+D, R = 128, 32
+
+API_NOTE = {
+    "fused": "mustafar_decode_attention (C ABI extension): key SpMV (+ window scores) -> softmax -> value SpMV (+ window p.V partials) -> sum, one call per layer",
+    "native": "the two reference entry points with un-padded (N=1) operands and a flat stream; PyTorch glue between them",
+    "reference": "exact reference call sequence: q/p zero-padded to 8 rows, torch.cat of per-head streams per call, 8-row outputs, PyTorch glue",
+}
 
 
 def parse():
@@ -49,12 +67,64 @@ def parse():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-api", action="store_true", help="skip the extra timings through the two reference entry points")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the c2/c4/c5 sub-results")
+    ap.add_argument("--no-trigger-leg", action="store_true", help="skip the 256-step leg that contains a compression trigger")
     ap.add_argument("--no-graph", action="store_true", help="fused api without hipGraph capture of the step")
     ap.add_argument("--api", default="fused", choices=["fused", "native", "reference"], help="call sequence timed for `value`")
     return ap.parse_args()
 
 
-def cache_bytes(past):
+# ------------------------------------------------------------------------------------------------ multi-GPU entry
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_replicas(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set), one per GPU.  This process has not touched the GPU and never does (torch.cuda.device_count() does not
+    initialise it on this image); rank 0's stdout is inherited, so its JSON line is this command's output."""
+    rehearse = os.environ.get("MUSTAFAR_BENCH_REHEARSE") == "1" or os.environ.get("MUSTAFAR_BENCH_DRYRUN") == "1"
+    if not rehearse:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but {have} GPU(s) are visible (MUSTAFAR_BENCH_REHEARSE=1 stacks the ranks on cuda:0 over gloo)", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:      # a dead rank leaves the others at a barrier: end them (our own children, by handle)
+                rc = code
+                for q in alive:
+                    q.terminate()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def kernel_source_tag() -> str:
+    """Identifies the kernels a PMC traffic figure was measured on (profiles/hbm_traffic.json carries the same tag)."""
+    h = hashlib.sha256()
+    for f in ("spmv.hip", "compress.hip"):
+        h.update(open(os.path.join(ROOT, "mustafar_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def ref_cache_bytes(past) -> int:
+    """Bytes of a cache in the reference layout (SURVEY 8d 'peak KV bytes'): bitmaps + offsets + streams + nz_offset + windows."""
     k_c, k_w, v_c, v_w, _, _ = past
     n = k_w.numel() * 2 + v_w.numel() * 2
     for c in (k_c, v_c):
@@ -63,7 +133,7 @@ def cache_bytes(past):
     return n
 
 
-def algorithmic_bytes(past, BH, which):
+def algorithmic_bytes(past, BH, which) -> int:
     """compressed bytes once per kv-head + dense operand in + result out, per launch."""
     c = past[0] if which == "key" else past[2]
     T = past[4]
@@ -72,7 +142,7 @@ def algorithmic_bytes(past, BH, which):
 
 class KernelTimer:
     """HIP events around every call of the two operators, recorded on torch's current stream -- the stream the
-    C ABI launches on."""
+    C ABI launches on (unfused call sequences only; the fused one has kernel timestamps inside the library)."""
 
     def __init__(self, mp):
         self.mp = mp
@@ -103,112 +173,119 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)) * 1e3, len(ev)
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    # rehearsal on a one-GPU box: MUSTAFAR_BENCH_REHEARSE=1 puts every rank on cuda:0 and lines them up over gloo
-    rehearse = os.environ.get("MUSTAFAR_BENCH_REHEARSE") == "1"
-    dev = torch.device("cuda", 0 if rehearse else local_rank)
-    torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist   # RCCL; used only for the barrier and the max-over-ranks of the time
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+class Workload:
+    """One BASELINE config resident on the device: per-layer caches (reference layout), fresh q/k/v per layer, and the
+    timed call sequences over them."""
 
-    from mustafar_amd import mustafar_package as mp
-    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    def __init__(self, name, layers, dev, rank, world, dist, rehearse, timer, lib):
+        from mustafar_amd.hook import MustafarAttention, MustafarConfig
+        self.name, self.layers, self.dev, self.world, self.dist, self.rehearse = name, layers, dev, world, dist, rehearse
+        self.timer, self.lib = timer, lib
+        self.label, self.Hq, self.Hkv, self.s, self.L, self.batch = CONFIGS[name]
+        self.T = ((self.L - R) // 256) * 256
+        self.BH = self.batch * self.Hq
+        torch.manual_seed(42 + rank)                       # seed of mem_spd_test.py:63 (+rank: replicas differ)
+        self.cfg = MustafarConfig(num_attention_heads=self.Hq, num_key_value_heads=self.Hkv, k_sparsity=self.s, v_sparsity=self.s,
+                                  residual_length=R, api="native")
+        self.attn = MustafarAttention(self.cfg)
+        self.pasts, self.qs, self.ks, self.vs = [], [], [], []
+        for _ in range(layers):
+            K = torch.randn(self.batch, self.Hkv, self.L, D, device=dev, dtype=torch.float32).half()
+            V = torch.randn(self.batch, self.Hkv, self.L, D, device=dev, dtype=torch.float32).half()
+            self.pasts.append(self.attn.build_cache(K, V))
+            del K, V
+            self.qs.append(torch.randn(self.batch, self.Hq, 1, D, device=dev).half())
+            self.ks.append(torch.randn(self.batch, self.Hkv, 1, D, device=dev).half())
+            self.vs.append(torch.randn(self.batch, self.Hkv, 1, D, device=dev).half())
+        self.ref_kv_bytes = sum(ref_cache_bytes(p) for p in self.pasts)
+        self.dense_bytes = layers * 2 * self.batch * self.Hkv * self.L * D * 2
+        self.alg_key = sum(algorithmic_bytes(p, self.BH, "key") for p in self.pasts) / layers
+        self.alg_val = sum(algorithmic_bytes(p, self.BH, "value") for p in self.pasts) / layers
+        self.extra = {}
 
-    label, Hq, Hkv, s, L, batch = CONFIGS[a.config]
-    D, R = 128, 32
-    T = ((L - R) // 256) * 256
-    BH = batch * Hq
-    torch.manual_seed(42 + rank)                       # seed of mem_spd_test.py:63 (+rank: replicas differ)
-    cfg = MustafarConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, k_sparsity=s, v_sparsity=s,
-                         residual_length=R, api="native")
-    attn = MustafarAttention(cfg)
-    timer = KernelTimer(mp)
-    timer.install()
+    # -- call sequences ---------------------------------------------------------------------------------------------
+    def one_step(self, state):
+        outs = []
+        for l in range(self.layers):
+            o, state[l] = self.attn.decode(self.qs[l], self.ks[l], self.vs[l], state[l])
+            outs.append(o)
+        return outs
 
-    # ---- build the per-layer caches (resident before the timed region) ------------------------------------------
-    torch.cuda.reset_peak_memory_stats(dev)
-    pasts, qs, ks, vs = [], [], [], []
-    for _ in range(a.layers):
-        K = torch.randn(batch, Hkv, L, D, device=dev, dtype=torch.float32).half()
-        V = torch.randn(batch, Hkv, L, D, device=dev, dtype=torch.float32).half()
-        pasts.append(attn.build_cache(K, V))
-        del K, V
-        qs.append(torch.randn(batch, Hq, 1, D, device=dev).half())
-        ks.append(torch.randn(batch, Hkv, 1, D, device=dev).half())
-        vs.append(torch.randn(batch, Hkv, 1, D, device=dev).half())
-    kv_bytes = sum(cache_bytes(p) for p in pasts)
-    dense_bytes = a.layers * 2 * batch * Hkv * L * D * 2
-    alg_key = algorithmic_bytes(pasts[0], BH, "key")
-    alg_val = algorithmic_bytes(pasts[0], BH, "value")
-    alg_key_all = sum(algorithmic_bytes(p, BH, "key") for p in pasts) / a.layers
-    alg_val_all = sum(algorithmic_bytes(p, BH, "value") for p in pasts) / a.layers
+    def fused_state(self):
+        self.cfg.api, self.cfg.arena = "fused", True
+        return [self.attn.to_fused(p) for p in self.pasts]
 
-    def one_step(state):
-        for l in range(a.layers):
-            _, state[l] = attn.decode(qs[l], ks[l], vs[l], state[l])
-
-    import ctypes
-    from mustafar_amd import _lib
-    lib = _lib.load()
-
-    from mustafar_amd.replicas import timed_region
-
-    def bracket(run_steps):
+    def bracket(self, run_steps):
         """barrier + synchronize on both sides, max over ranks (the contract's timed region)."""
-        return timed_region(run_steps, dist=dist, device=dev, reduce_on_cpu=rehearse)
+        from mustafar_amd.replicas import timed_region
+        return timed_region(run_steps, dist=self.dist, device=self.dev, reduce_on_cpu=self.rehearse)
 
-    def timed(api, steps, warmup):
+    def profile(self, run, records):
+        """Average key / value SpMV kernel duration (the kernels' own start / stop timestamps, what rocprofv3 reports) over `run`."""
+        from mustafar_amd import _lib
+        _lib.check(self.lib.mustafar_profile_begin(records), "mustafar_profile_begin")
+        run()
+        ku, vu, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(self.lib.mustafar_profile_end(ctypes.byref(ku), ctypes.byref(vu), ctypes.byref(n)), "mustafar_profile_end")
+        return ku.value, vu.value, n.value
+
+    def self_check(self):
+        """The timed call sequence (fused entry point over the arena cache) against the two reference entry points with
+        PyTorch glue, every layer, same inputs; fp16: 2 ulp of the output scale + 1e-4.  Returns the worst excess."""
+        fused = self.fused_state()
+        fused = [(p[0], p[1].clone(), p[2], p[3].clone(), p[4], p[5]) for p in fused]   # private windows: decode appends in place
+        got = self.one_step(fused)
+        self.cfg.api, self.cfg.arena = "native", False
+        want = self.one_step(list(self.pasts))
+        worst = 0.0
+        for g, w in zip(got, want):
+            scale = max(float(w.float().abs().max()), 2.0 ** -6)
+            err = float((g.float() - w.float()).abs().max())
+            if not math.isfinite(err):
+                return float("inf")
+            worst = max(worst, err / (2 * 2.0 ** -11 * scale + 1e-4))
+        del fused
+        return worst
+
+    def timed_eager(self, api, steps, warmup):
         """Eager call sequence `api`; per-kernel HIP events are recorded live inside the timed region."""
-        cfg.api = api
-        cfg.arena = api == "fused"
+        from mustafar_amd import _lib
+        self.cfg.api, self.cfg.arena = api, api == "fused"
         # decode() never mutates a reference-layout past in place; the fused api appends to its windows and to its
         # compressed cache in place, so it gets private copies (to_fused re-houses them in appendable buffers)
-        state = [attn.to_fused(p) for p in pasts] if api == "fused" else list(pasts)
+        state = self.fused_state() if api == "fused" else list(self.pasts)
         for _ in range(warmup):
-            one_step(state)
-        timer.reset()
-        timer.enabled = api != "fused"
+            self.one_step(state)
+        self.timer.reset()
+        self.timer.enabled = api != "fused"
         if api == "fused":
-            _lib.check(lib.mustafar_profile_begin(steps * a.layers), "mustafar_profile_begin")
-        dt = bracket(lambda: [one_step(state) for _ in range(steps)])
-        timer.enabled = False
+            _lib.check(self.lib.mustafar_profile_begin(steps * self.layers), "mustafar_profile_begin")
+        dt = self.bracket(lambda: [self.one_step(state) for _ in range(steps)])
+        self.timer.enabled = False
         if api == "fused":
             ku, vu, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-            _lib.check(lib.mustafar_profile_end(ctypes.byref(ku), ctypes.byref(vu), ctypes.byref(n)), "mustafar_profile_end")
-            kern = (ku.value, vu.value, n.value)
-        else:
-            kern = (timer.avg_us("key")[0], timer.avg_us("value")[0], len(timer.events["key"]))
-        return dt, kern
+            _lib.check(self.lib.mustafar_profile_end(ctypes.byref(ku), ctypes.byref(vu), ctypes.byref(n)), "mustafar_profile_end")
+            return dt, (ku.value, vu.value, n.value)
+        return dt, (self.timer.avg_us("key")[0], self.timer.avg_us("value")[0], len(self.timer.events["key"]))
 
-    def timed_graph(steps, warmup):
+    def timed_graph(self, steps, warmup, start_at_trigger_distance=None):
         """The fused call sequence of a whole step (all layers) captured ONCE into a hipGraph and replayed per step;
         a device-side counter grows the windows between replays.  A step that fires the 256-token compression
         trigger (model :324) runs eagerly and the graph is re-captured after it."""
-        cfg.api = "fused"
-        cfg.arena = True   # compressed cache in appendable storage: a 256-token trigger writes only the new tokens
-        state = [attn.to_fused(p) for p in pasts]
+        from mustafar_amd import _lib
+        attn, qs, ks, vs, layers, dev, lib = self.attn, self.qs, self.ks, self.vs, self.layers, self.dev, self.lib
+        state = self.fused_state()
         counter = torch.zeros(1, dtype=torch.int32, device=dev)
         warm = [(state[0][0], state[0][1].clone(), state[0][2], state[0][3].clone(), state[0][4], state[0][5])]
         attn.decode_fused(qs[0], ks[0], vs[0], warm[0])          # allocates the scratch buffers outside the capture
         torch.cuda.synchronize(dev)
-        box = {"g": None, "since": 0}
+        box = {"g": None, "since": 0, "triggers": 0}
 
         def capture():
             counter.zero_()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for l in range(a.layers):
+                for l in range(layers):
                     attn.decode_fused(qs[l], ks[l], vs[l], state[l], step_counter=counter)
                 _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream(dev).cuda_stream, counter.data_ptr(), 1), "counter_add")
             box["g"], box["since"] = g, 0
@@ -219,9 +296,10 @@ def main():
 
         def step():
             if until_trigger() == 1:
-                for l in range(a.layers):
+                for l in range(layers):
                     state[l] = attn.advance(state[l], box["since"])
-                one_step(state)                  # eager: prune + compress + append inside decode_fused
+                self.one_step(state)             # eager: prune + compress + append inside decode_fused
+                box["triggers"] += 1
                 capture()
             else:
                 box["g"].replay()
@@ -230,78 +308,177 @@ def main():
         capture()
         for _ in range(warmup):
             step()
-        dt = bracket(lambda: [step() for _ in range(steps)])
-        for l in range(a.layers):
+        dt = self.bracket(lambda: [step() for _ in range(steps)])
+        for l in range(layers):
             state[l] = attn.advance(state[l], box["since"])
-        # per-kernel HIP events: same steps again, eagerly, right after the timed replays (events cannot sit between
-        # the kernels of a replayed graph)
-        _lib.check(lib.mustafar_profile_begin(steps * a.layers), "mustafar_profile_begin")
-        for _ in range(steps):
-            one_step(state)
-        ku, vu, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-        _lib.check(lib.mustafar_profile_end(ctypes.byref(ku), ctypes.byref(vu), ctypes.byref(n)), "mustafar_profile_end")
-        extra["arena_reserved_bytes"] = int(sum(p[0].bytes_reserved() + p[2].bytes_reserved() + p[1].buf.numel() * 2 + p[3].buf.numel() * 2
-                                                for p in state))
-        return dt, (ku.value, vu.value, n.value)
+        # per-kernel durations: the same steps again, eagerly, right after the timed replays (kernel timestamps cannot be
+        # taken between the nodes of a replayed graph); rocprofv3 over the replays themselves agrees (profiles/)
+        nprof = min(steps, 10)
+        kern = self.profile(lambda: [self.one_step(state) for _ in range(nprof)], nprof * layers)
+        self.extra["arena_bytes_reserved"] = int(sum(p[0].bytes_reserved() + p[2].bytes_reserved() + p[1].buf.numel() * 2 + p[3].buf.numel() * 2
+                                                     for p in state))
+        self.extra["arena_bytes_in_use"] = int(sum(p[0].bytes_in_use() + p[2].bytes_in_use() + p[1].len * p[1].buf.shape[0] * p[1].buf.shape[1] * D * 2
+                                                   + p[3].len * p[3].buf.shape[0] * p[3].buf.shape[1] * D * 2 for p in state))
+        self.extra["triggers_in_timed_region"] = box["triggers"]
+        del state
+        return dt, kern
 
-    extra = {}
-    if a.api == "fused" and not a.no_graph:
-        dt, (key_us, val_us, n_key) = timed_graph(a.steps, a.warmup)
+    def roofline(self, key_us, val_us, n, traffic_file=True):
+        dom = "value" if val_us >= key_us else "key"
+        dom_us = max(val_us, key_us)
+        oth_us = min(val_us, key_us)
+        dom_bytes = self.alg_val if dom == "value" else self.alg_key
+        oth_bytes = self.alg_key if dom == "value" else self.alg_val
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
+        traffic, measured_at = None, None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch (tools/prof_traffic.sh)
+        if traffic_file and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                measured_at = tj.get("kernel_source_tag")
+                if measured_at == kernel_source_tag():               # only a figure measured on THESE kernels is reported
+                    traffic = tj.get(self.name, {}).get(dom)
+            except Exception:
+                traffic = None
+        return {"bound": "hbm", "kernel": f"{dom}_spmv_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_measured_at": measured_at, "kernel_source_tag": kernel_source_tag(),
+                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_timed": n,
+                "timing_source": "kernel start/stop timestamps (hipExtLaunchKernel events) of an eager pass over the same state "
+                                 "right after the timed graph replays; rocprofv3 --kernel-trace of the replays agrees (profiles/)",
+                "other": {"kernel": ("key" if dom == "value" else "value") + "_spmv_kernel", "avg_launch_us": round(oth_us, 2),
+                          "achieved": round(oth_bytes / (oth_us * 1e-6) / 1e9, 1), "frac": round(oth_bytes / (oth_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)},
+                "frac_of_measured_stream_ceiling_6290": round(achieved / 6290.0, 4)}
+
+
+def run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib):
+    """c2 / c4 / c5 as sub-results of the same line: fused + graph, a few steps, kernel fractions, a self-check."""
+    w = Workload(name, a.layers, dev, rank, world, dist, rehearse, timer, lib)
+    excess = w.self_check()
+    if not excess <= 1.0:
+        raise SystemExit(f"bench.py: self-check FAILED at {name}: fused vs reference entry points, {excess:.2f}x the fp16 bound")
+    steps = max(3, a.steps // 2)
+    dt, (ku, vu, n) = w.timed_graph(steps, 2)
+    rl = w.roofline(ku, vu, n, traffic_file=False)
+    out = {"workload": w.label, "value": round(world * w.batch * steps / dt, 2), "unit": "tokens/s", "ms_per_step": round(dt / steps * 1e3, 4),
+           "steps": steps, "self_check_excess": round(excess, 3),
+           "key_kernel_us": round(ku, 2), "value_kernel_us": round(vu, 2),
+           "key_frac": round(w.alg_key / (ku * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4), "value_frac": round(w.alg_val / (vu * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+           "roofline_frac": rl["frac"], "kv_bytes_reference_layout": int(w.ref_kv_bytes), "dense_kv_bytes": int(w.dense_bytes),
+           "arena_bytes_in_use": w.extra.get("arena_bytes_in_use"), "arena_bytes_reserved": w.extra.get("arena_bytes_reserved")}
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    a = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and a.gpus > 1:
+        sys.exit(spawn_replicas(a.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(world_env or "1")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    # rehearsal on a one-GPU box: MUSTAFAR_BENCH_REHEARSE=1 puts every rank on cuda:0 and lines them up over gloo
+    rehearse = os.environ.get("MUSTAFAR_BENCH_REHEARSE") == "1"
+    if os.environ.get("MUSTAFAR_BENCH_DRYRUN") == "1":     # CPU test of the launch plumbing: ranks, barrier, one line from rank 0
+        import torch.distributed as dist
+        from mustafar_amd.replicas import timed_region
+        if world > 1:
+            dist.init_process_group("gloo")
+        dt = timed_region(lambda: time.sleep(0.01), dist=dist if world > 1 else None, device=None)
+        if rank == 0:
+            print(json.dumps({"metric": "decode_tokens_per_sec", "n_gpus": world, "dry_run": True, "seconds": round(dt, 4)}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist   # RCCL; used only for the barrier and the max-over-ranks of the time
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    from mustafar_amd import _lib, mustafar_package as mp
+    lib = _lib.load()
+    timer = KernelTimer(mp)
+    timer.install()
+
+    torch.cuda.reset_peak_memory_stats(dev)
+    w = Workload(a.config, a.layers, dev, rank, world, dist, rehearse, timer, lib)
+
+    # ---- self-check of the call sequence about to be timed (untimed) ---------------------------------------------
+    excess = w.self_check()
+    if not excess <= 1.0:
+        raise SystemExit(f"bench.py: self-check FAILED: fused (arena) vs the two reference entry points differ by {excess:.2f}x the fp16 bound")
+
+    # ---- the timed region -----------------------------------------------------------------------------------------
+    use_graph = a.api == "fused" and not a.no_graph
+    if use_graph:
+        dt, (key_us, val_us, n_kern) = w.timed_graph(a.steps, a.warmup)
     else:
-        dt, (key_us, val_us, n_key) = timed(a.api, a.steps, a.warmup)
-    n_val = n_key
-    API_NOTE = {
-        "fused": "mustafar_decode_attention (C ABI extension): key SpMV (+ window scores) -> softmax -> value SpMV (+ window p.V partials) -> sum, one call per layer"
-                 + ("" if a.no_graph else "; the whole step captured once in a hipGraph and replayed"),
-        "native": "the two reference entry points with un-padded (N=1) operands and a flat stream; PyTorch glue between them",
-        "reference": "exact reference call sequence: q/p zero-padded to 8 rows, torch.cat of per-head streams per call, 8-row outputs, PyTorch glue",
-    }
+        dt, (key_us, val_us, n_kern) = w.timed_eager(a.api, a.steps, a.warmup)
+    main_extra = dict(w.extra)
+
     others = {}
     if not a.no_reference_api:
         for api in ("fused", "native", "reference"):
             if api == a.api and (api != "fused" or a.no_graph):
                 continue
             st_ = max(2, a.steps // 2)
-            dt_o, (ku, vu, _) = timed(api, st_, 1)
-            others[api] = {"value": round(world * batch * st_ / dt_o, 2), "unit": "tokens/s", "ms_per_step": round(dt_o / st_ * 1e3, 4),
+            dt_o, (ku, vu, _) = w.timed_eager(api, st_, 1)
+            others[api] = {"value": round(world * w.batch * st_ / dt_o, 2), "unit": "tokens/s", "ms_per_step": round(dt_o / st_ * 1e3, 4),
                            "key_call_us": round(ku, 2), "value_call_us": round(vu, 2),
-                           "note": (API_NOTE[api] if api != "fused" else API_NOTE[api].split(";")[0] + "; eager (no graph)")}
-    engine_extra = None
-    if not a.no_reference_api and a.api == "fused" and not a.no_graph and Hq // Hkv >= 4 and (Hq // Hkv) % 4 == 0:
-        # opt-in FMA engine (matrix pipe as a 4-wide FMA unit); NOT the headline: the north_star leaves MFMA off
+                           "note": API_NOTE[api] + ("; eager (no graph)" if api == "fused" else "")}
+
+    # ---- second engine: the matrix pipe as a 4-wide FMA unit (opt-in; the north_star leaves MFMA off) -------------------
+    engine_extra, roofline_mfma = None, None
+    if use_graph and w.Hq // w.Hkv >= 4 and (w.Hq // w.Hkv) % 4 == 0:
         _lib.check(lib.mustafar_set_fma_engine(1), "set_fma_engine")
-        st_ = max(2, a.steps // 2)
-        dt_e, (ku, vu, _) = timed_graph(st_, 1)
+        ex = w.self_check()
+        if not ex <= 1.0:
+            raise SystemExit(f"bench.py: self-check FAILED on the MFMA engine: {ex:.2f}x the fp16 bound")
+        dt_e, (ku, vu, ne) = w.timed_graph(a.steps, a.warmup)
         _lib.check(lib.mustafar_set_fma_engine(0), "set_fma_engine")
-        engine_extra = {"value": round(world * batch * st_ / dt_e, 2), "unit": "tokens/s", "ms_per_step": round(dt_e / st_ * 1e3, 4),
-                        "key_kernel_us": round(ku, 2), "value_kernel_us": round(vu, 2),
-                        "note": "same fused call sequence with MUSTAFAR_FMA_ENGINE=mfma (v_mfma_f32_4x4x4_16B_f16 as FMA unit); opt-in, off by default"}
+        roofline_mfma = w.roofline(ku, vu, ne, traffic_file=False)
+        engine_extra = {"value": round(world * w.batch * a.steps / dt_e, 2), "unit": "tokens/s", "ms_per_step": round(dt_e / a.steps * 1e3, 4),
+                        "steps": a.steps, "key_kernel_us": round(ku, 2), "value_kernel_us": round(vu, 2), "self_check_excess": round(ex, 3),
+                        "note": "same fused call sequence, same timed region, with MUSTAFAR_FMA_ENGINE=mfma (v_mfma_f32_4x4x4_16B_f16 as a 4-wide FMA unit; "
+                                "nothing dense is built); opt-in, off by default"}
+
+    # ---- >= 256 consecutive steps: the 256-token compression trigger (prune + compress + in-place append) included --------
+    trig = None
+    if use_graph and not a.no_trigger_leg:
+        nst = 256
+        dt_t, _ = w.timed_graph(nst, 1)
+        trig = {"value": round(world * w.batch * nst / dt_t, 2), "unit": "tokens/s", "steps": nst, "ms_per_step": round(dt_t / nst * 1e3, 4),
+                "triggers": w.extra.get("triggers_in_timed_region"),
+                "note": "the trigger step runs eagerly (prune + compress + arena append of 256 tokens per head and layer) and the step graph is re-captured after it"}
     alloc_peak = torch.cuda.max_memory_allocated(dev)
+
+    # ---- the other BASELINE configs as sub-results (N = 1) -----------------------------------------------------------
+    label, Hq, Hkv, s, L, batch, T = w.label, w.Hq, w.Hkv, w.s, w.L, w.batch, w.T
+    roofline = w.roofline(key_us, val_us, n_kern) if rank == 0 else None
+    ref_kv, dense_bytes = w.ref_kv_bytes, w.dense_bytes
+    sub = {}
+    if world == 1 and not a.no_other_configs and a.api == "fused" and not a.no_graph:
+        del w
+        torch.cuda.empty_cache()
+        for name in ("c2", "c4", "c5"):
+            if name != a.config:
+                sub[name] = run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib)
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-
-    # ---- roofline of the dominant kernel (HIP events recorded live in the timed region above) ------------------
-    dom = "value" if val_us >= key_us else "key"
-    dom_us = max(val_us, key_us)
-    dom_bytes = alg_val_all if dom == "value" else alg_key_all
-    achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, measured offline
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(a.config, {}).get(dom)
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": f"{dom}_spmv_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_timed": n_val if dom == "value" else n_key,
-                "other": {"kernel": ("key" if dom == "value" else "value") + "_spmv_kernel",
-                          "avg_launch_us": round(min(val_us, key_us), 2),
-                          "achieved": round((alg_key_all if dom == "value" else alg_val_all) / (min(val_us, key_us) * 1e-6) / 1e9, 1)},
-                "frac_of_measured_stream_ceiling_6290": round(achieved / 6290.0, 4)}
 
     # ---- host-CPU dense baseline (oracle/dense_ref.py: the reference's dense pruned path), bounded sample --------
     cpu = None
@@ -315,20 +492,27 @@ def main():
                "sample": f"{sample_layers} of {a.layers} layers of the same workload ({label}), dense pruned q.K^T/sqrt(d) -> fp32 softmax -> p.V "
                          f"in PyTorch on the host ({how}), median of {reps} runs after a probe, scaled x{a.layers}/{sample_layers}"}
 
+    timed_kv = main_extra.get("arena_bytes_in_use") if use_graph else ref_kv
     out = {
         "metric": "decode_tokens_per_sec", "value": round(world * batch * a.steps / dt, 2), "unit": "tokens/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": label, "id": a.config, "layers": a.layers, "q_heads": Hq, "kv_heads": Hkv, "head_dim": D,
                    "sparsity": s, "seq_len": L, "compressed_tokens": T, "batch_per_gpu": batch, "residual_length": R,
-                   "api": a.api, "api_note": API_NOTE[a.api], "fma_engine": "valu (v_fma_mix_f32; MFMA off)",
-                   "parallelism": f"replicas x{world}"},
-        "peak_kv_bytes": int(kv_bytes), "dense_kv_bytes": int(dense_bytes), "kv_compression_ratio": round(dense_bytes / kv_bytes, 3),
+                   "api": a.api, "api_note": API_NOTE[a.api] + ("; the whole step captured once in a hipGraph and replayed" if use_graph else ""),
+                   "fma_engine": "valu (v_fma_mix_f32; MFMA off)", "parallelism": f"replicas x{world}"},
+        "self_check": {"passed": True, "excess_over_fp16_bound": round(excess, 3),
+                       "what": "every layer's output of the timed call sequence (fused entry point, arena cache) vs the two reference entry "
+                               "points with PyTorch glue on the same inputs; bound = 2 ulp of the output scale + 1e-4"},
+        "peak_kv_bytes": int(timed_kv), "peak_kv_bytes_note": "bytes IN USE of the container the timed leg ran on (arena rows + stream regions + windows)",
+        "kv_bytes_reserved": main_extra.get("arena_bytes_reserved"), "kv_bytes_reference_layout": int(ref_kv),
+        "dense_kv_bytes": int(dense_bytes), "kv_compression_ratio": round(dense_bytes / timed_kv, 3),
+        "kv_compression_ratio_reserved": round(dense_bytes / main_extra["arena_bytes_reserved"], 3) if main_extra.get("arena_bytes_reserved") else None,
         "allocator_peak_bytes": int(alloc_peak),
-        "allocator_note": "peak of the whole bench process: the reference-layout caches kept for the other call sequences + the "
-                          "appendable (arena) copy the timed fused leg runs on + transients; arena_reserved_bytes = what the fused leg holds",
-        "arena_reserved_bytes": extra.get("arena_reserved_bytes"),
-        "roofline": roofline, "cpu_baseline": cpu, "other_call_sequences": others, "fma_engine_mfma": engine_extra,
+        "allocator_note": "peak of the whole bench process: the reference-layout caches kept for the other call sequences and the self-check + "
+                          "the appendable (arena) copy the timed fused leg runs on + transients",
+        "roofline": roofline, "roofline_mfma": roofline_mfma, "cpu_baseline": cpu, "other_call_sequences": others,
+        "fma_engine_mfma": engine_extra, "tokens_per_sec_incl_trigger": trig, "configs": sub,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -20,6 +20,13 @@ import torch
 from . import _lib
 
 
+# Spare capacity of a new arena: rows for two more 256-token appends, stream regions 3 % over the fullest head's measured
+# bytes per token (the heads of one layer differ by < 1 % on i.i.d. data; an append that does not fit re-houses the cache).
+# Round 1 reserved t + 1024 tokens x 1.08 = 22 % over the bytes in use at c3; this is ~10 %.
+DEFAULT_EXTRA_TOKENS = 512
+DEFAULT_HEADROOM = 1.03
+
+
 class CompressedArena:
     TILES_PER_TOKEN = 2   # head_dim 128 / 64
 
@@ -82,8 +89,9 @@ class CompressedArena:
             x = x.contiguous()
         t = x.shape[1]
         L = _lib.load()
-        if self.tokens + t > self.cap_tokens:
-            self._grow(_round_up(max(2 * self.cap_tokens, self.tokens + t), 256), self.nz_cap)
+        if self.tokens + t > self.cap_tokens:   # rows full: a quarter more (at least 1024 tokens), the stream regions in proportion
+            cap = _round_up(max(self.cap_tokens + max(1024, self.cap_tokens // 4), self.tokens + t), 256)
+            self._grow(cap, _round_up(int(self.nz_cap * (cap / float(self.cap_tokens))) + 8, 8))
         st = torch.cuda.current_stream(self.device).cuda_stream
         key = self.which == "key"
         with torch.cuda.device(self.device):
@@ -103,11 +111,11 @@ class CompressedArena:
 
     # ---- conversion ------------------------------------------------------------------------------------------
     @classmethod
-    def from_pruned(cls, x: torch.Tensor, which: str, cap_tokens: Optional[int] = None, headroom: float = 1.08) -> "CompressedArena":
-        """Compress x [B', t, 128] (already pruned) into a new arena sized for `cap_tokens` (default: t + 1024) with
-        stream regions of `headroom` x the measured halfs per token."""
+    def from_pruned(cls, x: torch.Tensor, which: str, cap_tokens: Optional[int] = None, headroom: float = DEFAULT_HEADROOM) -> "CompressedArena":
+        """Compress x [B', t, 128] (already pruned) into a new arena sized for `cap_tokens` (default: t + DEFAULT_EXTRA_TOKENS)
+        with stream regions of `headroom` x the measured halfs per token."""
         heads, t, _ = x.shape
-        cap = _round_up(cap_tokens if cap_tokens else t + 1024, 256)
+        cap = _round_up(cap_tokens if cap_tokens else t + DEFAULT_EXTRA_TOKENS, 256)
         # first pass into rows of exactly t tokens and a generous guess for the streams (dense would be 128 halfs per
         # token), then re-house at the measured size: the transient is freed, the resident footprint is tight
         a = cls(heads, which, x.device, _round_up(t, 64), _round_up(t * 72 + 1024, 8))
@@ -120,13 +128,13 @@ class CompressedArena:
 
     @classmethod
     def from_reference(cls, compressed: list, which: str, tokens: int, cap_tokens: Optional[int] = None,
-                       headroom: float = 1.08) -> "CompressedArena":
+                       headroom: float = DEFAULT_HEADROOM) -> "CompressedArena":
         """Re-house a reference-layout cache `[bitmaps, idxs, nzs, nz_offset]` holding `tokens` tokens per head."""
         bmp, idx, nzs, _ = compressed
         heads = len(nzs)
         t = tokens * cls.TILES_PER_TOKEN
         used = torch.tensor([n.numel() for n in nzs], dtype=torch.int64)
-        cap = _round_up(cap_tokens if cap_tokens else tokens + 1024, 256)
+        cap = _round_up(cap_tokens if cap_tokens else tokens + DEFAULT_EXTRA_TOKENS, 256)
         per_token = float(used.max()) / max(tokens, 1)
         a = cls(heads, which, bmp.device, cap, _round_up(int(per_token * cap * headroom) + 1024, 8))
         a.bmp[:, :t] = bmp.view(heads, t)

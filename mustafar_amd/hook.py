@@ -43,6 +43,8 @@ class MustafarConfig:
     group_size: int = 32          # carried by the reference config, unused on the kernel path
     api: str = "native"           # "reference" | "native" | "fused"
     arena: bool = False           # api="fused": keep the compressed cache in CompressedArena objects (in-place append)
+    arena_extra_tokens: int = 512   # spare token rows of a new arena; its stream regions get arena_headroom x the
+    arena_headroom: float = 1.03    # fullest head's bytes per token (cache.py: DEFAULT_EXTRA_TOKENS / DEFAULT_HEADROOM)
 
 
 def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:
@@ -169,8 +171,9 @@ class MustafarAttention:
             k_pruned = self.dh_prune_key(key_states[:, :, :compressed_length, :])                     # :419
             v_pruned = self.dh_prune_value(value_states[:, :, :compressed_length, :])                 # :420
             if self.cfg.arena and self.cfg.api == "fused":   # straight into appendable storage
-                k_compressed = CompressedArena.from_pruned(k_pruned.reshape(total_batch_kv, -1, D), "key")
-                v_compressed = CompressedArena.from_pruned(v_pruned.reshape(total_batch_kv, -1, D), "value")
+                cap, hr = compressed_length + self.cfg.arena_extra_tokens, self.cfg.arena_headroom
+                k_compressed = CompressedArena.from_pruned(k_pruned.reshape(total_batch_kv, -1, D), "key", cap, hr)
+                v_compressed = CompressedArena.from_pruned(v_pruned.reshape(total_batch_kv, -1, D), "value", cap, hr)
             else:
                 k_compressed = _compress(k_pruned.reshape(total_batch_kv, -1, D), "key")              # :422-426
                 v_compressed = _compress(v_pruned.reshape(total_batch_kv, -1, D), "value")            # :430-434
@@ -192,8 +195,8 @@ class MustafarAttention:
         """Wrap the two local windows of a reference-layout `past` into appendable buffers."""
         k_c, k_w, v_c, v_w, C, L = past
         if self.cfg.arena and C and not isinstance(k_c, CompressedArena):
-            k_c = CompressedArena.from_reference(k_c, "key", C)
-            v_c = CompressedArena.from_reference(v_c, "value", C)
+            k_c = CompressedArena.from_reference(k_c, "key", C, C + self.cfg.arena_extra_tokens, self.cfg.arena_headroom)
+            v_c = CompressedArena.from_reference(v_c, "value", C, C + self.cfg.arena_extra_tokens, self.cfg.arena_headroom)
         if isinstance(k_w, Window):
             return (k_c, k_w, v_c, v_w, C, L)
         cap = self.cfg.residual_length + 256 + 64
@@ -282,7 +285,8 @@ class MustafarAttention:
             v_blk = self.dh_prune_value(v_w.buf[:, :, :256, :]).reshape(Bkv, -1, D)                     # :326
             if use_arena or (cfg.arena and C == 0):
                 if C == 0:
-                    k_c, v_c = CompressedArena.from_pruned(k_blk, "key"), CompressedArena.from_pruned(v_blk, "value")
+                    k_c = CompressedArena.from_pruned(k_blk, "key", 256 + cfg.arena_extra_tokens, cfg.arena_headroom)
+                    v_c = CompressedArena.from_pruned(v_blk, "value", 256 + cfg.arena_extra_tokens, cfg.arena_headroom)
                 else:
                     k_c.append(k_blk)                                                                   # :339-390, in place
                     v_c.append(v_blk)
