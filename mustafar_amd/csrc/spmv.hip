@@ -270,6 +270,11 @@ __device__ __forceinline__ void gather_wait(Gathered& g, u32x4 (&c)[G])
 
 // acc[h] += tile element x coefficient for the 8 gathered tiles.  The FMAs of tile j run under EXEC = its
 // bitmap, so lanes whose element is zero are untouched: no v_cndmask and no clean gather result needed.
+// EXEC contract (fma8 and gather8_clean): the statement loads EXEC with bitmaps and restores it with -1, declares no
+// clobber, and therefore requires a FULL wave at entry: workgroups are multiples of 64 threads (static_asserts below)
+// and every call site is wave-uniform.  tools/check_smem_hazards.py verifies on the generated ISA that each such
+// statement restores EXEC before it ends and never sits inside a compiler-made divergent region.
+static_assert(kThreads % 64 == 0, "the asm helpers restore EXEC to a full wave");
 template <int G>
 __device__ __forceinline__ void fma8(const u32x4 (&c)[G], const Gathered& g, float (&acc)[G])
 {
@@ -1474,7 +1479,9 @@ int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const v
 int mustafar_value_pick_split_k(int M_Global, int N_Global, int K_Global, int Batch_Size, int num_key_value_groups)
 {
     (void)N_Global;
-    if (M_Global != kD || K_Global <= 0 || (K_Global & 63) || num_key_value_groups < 1 || Batch_Size < 1) return 1;
+    if (M_Global != kD || K_Global <= 0 || (K_Global & 63) || num_key_value_groups < 1 || Batch_Size < num_key_value_groups ||
+        Batch_Size % num_key_value_groups)
+        return 1;   // (arguments Value_SplitK_API rejects: no split, no division by an empty grid)
     const int ntb = K_Global / 64;
     const int G = pick_g(num_key_value_groups);
     const int gy = (Batch_Size / num_key_value_groups) * (num_key_value_groups / G);
@@ -1492,7 +1499,9 @@ int64_t mustafar_value_workspace_bytes(int M_Global, int N_Global, int K_Global,
                                        int num_key_value_groups, int Split_K)
 {
     (void)K_Global;
-    if (Split_K <= 1) return 0;
+    if (Split_K <= 1 || num_key_value_groups < 1 || Batch_Size < num_key_value_groups || Batch_Size % num_key_value_groups ||
+        N_Global < 1 || M_Global < 1)
+        return 0;
     const int G = pick_g(num_key_value_groups);
     const int64_t gy = (int64_t)(Batch_Size / num_key_value_groups) * (num_key_value_groups / G);
     const int64_t slabs = (int64_t)Split_K * Batch_Size * N_Global * M_Global * (int64_t)sizeof(float);
@@ -1653,7 +1662,13 @@ int mustafar_profile_begin(int max_records)
     if (g_prof.ev || max_records < 1) return MUSTAFAR_EINVAL;
     g_prof.ev = new hipEvent_t[4 * (size_t)max_records];
     for (int i = 0; i < 4 * max_records; i++)
-        if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return (int)hipGetLastError();
+        if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) {   // release what exists: a failed begin leaves no state behind
+            const int err = (int)hipGetLastError();
+            for (int j = 0; j < i; j++) (void)hipEventDestroy(g_prof.ev[j]);
+            delete[] g_prof.ev;
+            g_prof = Profile();
+            return err ? err : MUSTAFAR_EINVAL;
+        }
     g_prof.cap = max_records;
     g_prof.n = 0;
     g_prof.on = true;

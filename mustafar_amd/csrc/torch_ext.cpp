@@ -8,7 +8,6 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <stdexcept>
-#include <unordered_map>
 
 #include "../../include/mustafar_hip.h"
 
@@ -48,8 +47,6 @@ void cache_checks(const torch::Tensor& bmp, const torch::Tensor& idx, const torc
                 "compressed cache does not match the arguments: expected ", heads, " heads x ", tiles, " tiles");
 }
 
-std::unordered_map<int, torch::Tensor> g_workspace;   // per device; grows on demand (the GIL serialises callers)
-
 }  // namespace
 
 torch::Tensor mustafar_key_formulation(torch::Tensor bmp, torch::Tensor NZ, torch::Tensor idx, torch::Tensor NZ_Offset, torch::Tensor B,
@@ -85,12 +82,13 @@ torch::Tensor mustafar_value_formulation(torch::Tensor bmp, torch::Tensor NZ, to
     c10::hip::HIPGuardMasqueradingAsCUDA guard(B.device());   // PyTorch-ROCm presents HIP devices as "cuda"
     const int split = mustafar_value_pick_split_k(M_Global, N, K_Global, Batch_Size, num_key_value_groups);
     const int64_t need = mustafar_value_workspace_bytes(M_Global, N, K_Global, Batch_Size, num_key_value_groups, split);
+    // fp32 partial slabs of THIS call, from the caching allocator like the output (the reference allocates per call too,
+    // mustafar_wrapper.cu:81/:202): stream-ordered reuse, nothing shared between streams or threads
+    torch::Tensor slabs;
     void* ws = nullptr;
     if (need > 0) {
-        auto& t = g_workspace[B.device().index()];
-        if (!t.defined() || t.numel() < need)
-            t = torch::empty({std::max<int64_t>(need, 1 << 20)}, torch::TensorOptions().dtype(torch::kUInt8).device(B.device()));
-        ws = t.data_ptr();
+        slabs = torch::empty({need}, torch::TensorOptions().dtype(torch::kUInt8).device(B.device()));
+        ws = slabs.data_ptr();
     }
     auto C = torch::empty({Batch_Size, N, M_Global}, B.options());
     const int err = Value_SplitK_API(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(), nullptr,

@@ -27,7 +27,17 @@ def _native_built():
     lib = os.path.join(ROOT, "mustafar_amd", "lib", "libmustafar_hip.so")
     ext = glob.glob(os.path.join(ROOT, "mustafar_amd", "dropin", "mustafar_package*.so"))
     orc = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not (os.path.exists(lib) and ext and os.path.exists(orc)):
-        import __graft_entry__
+    import __graft_entry__
+
+    def stale():
+        if not (os.path.exists(lib) and ext and os.path.exists(orc)):
+            return True
+        # a stale binary must not be tested against newer sources: build() leaves the hash of its sources next to the library
+        try:
+            return open(__graft_entry__.STAMP).read().strip() != __graft_entry__.native_source_hash()
+        except OSError:
+            return True
+
+    if stale():
         __graft_entry__.build()
     yield
