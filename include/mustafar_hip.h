@@ -74,12 +74,12 @@ int mustafar_prune_magnitude(void* stream, const void* x, void* out, int64_t n_r
 
 /*
  * Compression.  Replaces `convert_key_batched` / `convert_value_batched` (kernel/compression.py:249-432)
- * as two device passes with one small device->host read between them (the reference needs >= 1 + 2B'):
+ * as two device passes (each ONE read of x) with one small device->host read between them (the reference needs >= 1 + 2B'):
  *   pass 1  mustafar_compress_bitmap_{key,value}: x fp16 [B', t, D] (already pruned) ->
  *           bmp i64 [B', t*D/64], accum i32 [B', t*D/64 + 1] (accum_counts, compression.py:294-298) and
  *           head_off i64 [B'+1] = exclusive prefix of 2*accum[h][-1] (start of each head in halfs; :302-304).
  *   pass 2  mustafar_compress_pack_{key,value}: writes every half of nz_flat[0 .. head_off[B'])
- *           (non-zeros and zero padding; no pre-zeroing needed).
+ *           (non-zeros and zero padding; no pre-zeroing needed); packs x by the bitmaps of pass 1.
  */
 int mustafar_compress_bitmap_key(void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
                                  int64_t* head_off);
@@ -166,6 +166,29 @@ int mustafar_cache_append_pack_key(void* stream, const void* x, int Bp, int t, i
 int mustafar_cache_append_pack_value(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
                                      int old_tokens);
 int mustafar_counter_add(void* stream, int32_t* counter, int delta);
+
+/*
+ * The whole 256-token trigger of the hook (models/llama_mustafar_kernel.py:324-398) for K and V together, from the RAW
+ * window rows: prune (:325-326, kth = max(1, int(sparsity * D)); 0 = rows already pruned), compress (:328-337) and append
+ * (:339-390) in three launches -- pass 1 (thresholds in registers, bitmaps, counts) for both sides, one scan, pass 2 (pack
+ * from the raw rows by the bitmaps) for both sides.  No pruned copy is written, nothing is allocated and nothing is read
+ * back on the host, so the call can be captured in a hipGraph.  The same call compresses a prefill block (:416-437) into
+ * two empty views (old_tokens = 0).
+ *   k_x / v_x       fp16 rows of 128; head h starts `head_stride` elements after head h - 1 (a window buffer: capacity * 128)
+ *   *_head_total    i64 [B'] out: every head's new stream length in halfs (read it whenever convenient, e.g. through an
+ *                   asynchronous copy: the next append needs it only to decide about room)
+ *   *_region_halfs  room of a head's stream region (0 = unchecked); overflow_flag (device int, may be NULL): set when a head
+ *                   outgrows its region -- pass 2 then writes NOTHING (bitmaps / offsets of the new tokens are there, the
+ *                   streams are not): re-house and repeat.  Callers keep room for one worst-case append (t * 128 halfs).
+ *   scratch         mustafar_compress_scratch_bytes(B', t) bytes
+ */
+int64_t mustafar_compress_scratch_bytes(int Bp, int t);
+int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int64_t head_stride, int Bp, int t, int D, int kth_k,
+                             int kth_v, const mustafar_cache_view* k_dst, const mustafar_cache_view* v_dst, int old_tokens,
+                             int64_t* k_head_total, int64_t* v_head_total, int64_t k_region_halfs, int64_t v_region_halfs,
+                             int32_t* overflow_flag, void* scratch);
+/* Window slide of the trigger (model :392-393) in place: rows [drop, len) of every head move to the front (at most 64 rows stay). */
+int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int64_t head_stride, int Bp, int len, int drop);
 
 /*
  * FMA engine of the GQA-4 SpMV kernels: 0 = VALU v_fma_mix_f32 (default; MFMA left off as the north_star asks),

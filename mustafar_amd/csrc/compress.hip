@@ -91,70 +91,232 @@ __global__ __launch_bounds__(64) void prune_magnitude_kernel(const uint32_t* __r
     }
 }
 
-// ------------------------------------------------------------------------------------------------ bitmaps
-// Destination rows of the passes: the reference's contiguous result tensors (bmp [B', 2t], accum [B', 2t + 1], stride =
-// row length, tile0 = 0) or rows of a cache view with spare capacity, written behind the tiles already in use
-// (in-place append: mustafar_cache_append_*).
+// ------------------------------------------------------------------------------------------------ compression
+// Two passes over the dense block, each ONE read of it (round 1 took three reads and one write: prune, bitmaps, pack):
+//   pass 1  tile_meta_kernel : raw rows -> [per-row prune threshold, in registers] -> bitmaps, padded counts, the prefix
+//                              of the counts inside the 64-token block, the block's total.  Nothing pruned is written.
+//           block_scan_kernel: one workgroup per head turns the block totals into every block's base (+ head totals).
+//   pass 2  tile_pack_kernel : raw rows + the bitmaps -> packed stream; adds the block's base to the block-local prefix
+//                              (the offsets the SpMV kernels read).  A kept value IS the raw value, so the bitmap alone
+//                              says what to pack: no pruned copy of the block exists anywhere.
+// Destination rows: the reference's contiguous result tensors (bmp [B', 2t], accum [B', 2t + 1], stride = row length,
+// tile0 = 0) or rows of a cache view with spare capacity, written behind the tiles already in use (in-place append).
 struct Rows {
     int64_t bmp_stride;   // elements between the heads' bitmap rows
     int64_t idx_stride;   // elements between the heads' offset rows
     int64_t tile0;        // first tile of a row this call writes (2 * old_tokens)
 };
 
-// grid: x = token block (64 tokens), y = head.  Writes the 128 bitmaps of the block and the raw padded
-// counts (half2 units) into accum[h][tile + 1]; the scan kernel turns them into the exclusive prefix.
+// One side (K or V) of a pass-1 / pass-2 launch; a launch carries up to two sides in grid.z (the trigger compresses the
+// 256 oldest window tokens of K and V with three launches in all).
+struct Side {
+    const uint16_t* x;          // rows of 128 halfs; head h starts at x + h * head_stride (a window buffer has spare rows)
+    int64_t head_stride;        // elements
+    int64_t* bmp;               // [B', rows.bmp_stride]
+    int32_t* accum;             // [B', rows.idx_stride]
+    int32_t* blk;               // [B', ntb] block totals (pass 1) -> block bases (scan); pass 2: nullptr = accum is final
+    int64_t* totals;            // [B'] (+1 with the exclusive prefix) stream length of every head in halfs
+    const int64_t* head_off;    // pass 2: start of every head's stream in halfs (fresh result tensor) ...
+    const uint32_t* nz_offset;  //         ... or in uint4 units (cache view)
+    uint16_t* nz;
+    Rows rows;
+    int64_t region_halfs;       // > 0: a head's stream may not grow beyond this (cache view); checked by the scan
+    int kth;                    // > 0: prune first (k-th smallest magnitude, model :97-110); 0: rows are already pruned
+    int key;                    // tile geometry: 1 = K (64 tokens of a channel), 0 = V (64 channels of a token)
+};
 
-// The 128 raw counts of a token block (threads 0..127 hold one each) -> inclusive prefix inside the block, written to
-// accum[...][tile + 1], and the block's total to blk_total.  Two waves: wave scan + the first wave's total.
-__device__ __forceinline__ void block_prefix_store(int32_t cnt, int32_t* __restrict__ accum_row, int64_t tile_in_row,
-                                                   int32_t* __restrict__ blk_total_slot, int32_t* s_tot)
+// v_writelane_b32 with the lane as an immediate (two SGPR operands would break the constant-bus rule; this clang has no
+// builtin for the instruction).
+template <int LANE>
+__device__ __forceinline__ void write_lane(uint32_t& dst, uint32_t src)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t v = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t u = __shfl_up(v, o);
-        if (lane >= o) v += u;
-    }
-    if (threadIdx.x == 63) *s_tot = v;
-    __syncthreads();
-    if (wave == 1) v += *s_tot;
-    if (threadIdx.x < kD) accum_row[tile_in_row + 1] = v;
-    if (threadIdx.x == kD - 1) *blk_total_slot = v;
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(src), "i"(LANE));
 }
 
-// V: tile (tb, half, r) = channels half*64..+63 of token tb*64+r (compression.py:87-97); lane = channel.
-__global__ __launch_bounds__(kThreads) void bitmap_value_kernel(const uint16_t* __restrict__ x, int t, int64_t* __restrict__ bmp,
-                                                                int32_t* __restrict__ accum, int32_t* __restrict__ blk_total,
-                                                                Rows rows)
+// K geometry of pass 1: tile d = flag d of the 64 rows -> one ballot each; the mask of tile d goes to lane d % 64 (first
+// 64 tiles: a, the others: b).  Compile-time recursion over the flag registers (the lane operand must be an immediate).
+template <int J>
+__device__ __forceinline__ void key_masks(const uint32_t (&f)[kD / 2], uint32_t& a_lo, uint32_t& a_hi, uint32_t& b_lo, uint32_t& b_hi)
 {
-    __shared__ uint64_t s_bmp[kD];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tb = blockIdx.x, h = blockIdx.y;
-    const uint16_t* xb = x + ((int64_t)h * t + (int64_t)tb * 64) * kD;
-    for (int r = wave; r < 64; r += kWaves) {
-        const uint16_t a = xb[r * kD + lane], b = xb[r * kD + 64 + lane];
-        const uint64_t m0 = __builtin_bitreverse64(__ballot(nonzero_h(a)));
-        const uint64_t m1 = __builtin_bitreverse64(__ballot(nonzero_h(b)));
-        if (lane == 0) {
-            s_bmp[r]      = m0;
-            s_bmp[64 + r] = m1;
+    if constexpr (J < kD / 2) {
+        const uint64_t m0 = __builtin_bitreverse64(__ballot((f[J] & 1u) != 0));    // element 2J
+        const uint64_t m1 = __builtin_bitreverse64(__ballot((f[J] >> 16) != 0));   // element 2J + 1
+        if constexpr (2 * J < 64) {
+            write_lane<2 * J>(a_lo, (uint32_t)m0);     write_lane<2 * J>(a_hi, (uint32_t)(m0 >> 32));
+            write_lane<2 * J + 1>(a_lo, (uint32_t)m1); write_lane<2 * J + 1>(a_hi, (uint32_t)(m1 >> 32));
+        } else {
+            write_lane<2 * J - 64>(b_lo, (uint32_t)m0); write_lane<2 * J - 64>(b_hi, (uint32_t)(m0 >> 32));
+            write_lane<2 * J - 63>(b_lo, (uint32_t)m1); write_lane<2 * J - 63>(b_hi, (uint32_t)(m1 >> 32));
+        }
+        key_masks<J + 1>(f, a_lo, a_hi, b_lo, b_hi);
+    }
+}
+
+// Pass 1.  One wave per 64-token block, lane = row (token): the row sits in 64 VGPRs (16 loads of 16 bytes; the lanes of
+// one instruction touch 64 different lines, the next 7 instructions hit them in L1).  No LDS: 6-8 waves per SIMD hide the
+// loads, where the LDS-transposed prune kernel runs 9 waves per CU.
+//   K tile d   = element d of the 64 rows   -> one ballot; the 128 masks are handed to lanes d % 64 by v_writelane
+//   V tiles    = the lane's own row halves  -> the lane packs its 2 x 64 flags itself (4 VALU ops per register)
+// Either way lane l ends up owning tiles l and 64 + l of the block: counts, two wave scans, two coalesced stores.
+__global__ __launch_bounds__(64, 6) void tile_meta_kernel(Side s0, Side s1, int ntb)
+{
+    const bool z = blockIdx.z != 0;
+    const uint16_t* x = z ? s1.x : s0.x;
+    const int64_t head_stride = z ? s1.head_stride : s0.head_stride;
+    int64_t* bmp = z ? s1.bmp : s0.bmp;
+    int32_t* accum = z ? s1.accum : s0.accum;
+    int32_t* blk = z ? s1.blk : s0.blk;
+    const Rows rows = z ? s1.rows : s0.rows;
+    const int kth = z ? s1.kth : s0.kth;
+    const int key = z ? s1.key : s0.key;
+    const int lane = threadIdx.x, tb = blockIdx.x, h = blockIdx.y;
+    const uint32_t H = 0x80008000u, ONES = 0x00010001u;
+
+    const uint4* src = reinterpret_cast<const uint4*>(x + h * head_stride + ((int64_t)tb * 64 + lane) * kD);
+    uint32_t w[kD / 2];   // magnitudes with the guard bits set
+#pragma unroll
+    for (int p = 0; p < kD / 8; p++) {
+        const uint4 v = src[p];
+        w[4 * p] = v.x; w[4 * p + 1] = v.y; w[4 * p + 2] = v.z; w[4 * p + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < kD / 2; j++)   // guard bits IN PLACE (a plain `| H` gets fresh registers: 128 live instead of 64)
+        asm("v_or_b32 %0, %1, %0" : "+v"(w[j]) : "s"(H));
+    uint32_t thr = 0;   // 0 keeps everything (rows already pruned)
+    if (kth > 0) {      // bit-by-bit search of the k-th smallest magnitude, as prune_magnitude_kernel
+#pragma unroll 1
+        for (int bit = 14; bit >= 0; bit--) {
+            const uint32_t c = thr | (1u << bit);
+            const uint32_t cc = c | (c << 16);
+            uint32_t ge = 0;
+#pragma unroll
+            for (int j = 0; j < kD / 2; j++) ge += ((w[j] - cc) >> 15) & ONES;
+            const int below = kD - (int)((ge & 0xffffu) + (ge >> 16));
+            if (below < kth) thr = c;
         }
     }
-    __syncthreads();
-    __shared__ int32_t s_tot;
-    int32_t cnt = 0;
-    const int64_t tile = (int64_t)tb * kD + (threadIdx.x & (kD - 1));
-    if (threadIdx.x < kD) {
-        const uint64_t m = s_bmp[threadIdx.x];
-        bmp[h * rows.bmp_stride + rows.tile0 + tile] = (int64_t)m;
-        cnt = ((__popcll(m) + 7) & ~7) >> 1;   // compression.py:46-48
+    // f[j]: bit 0 / bit 16 set iff element 2j / 2j + 1 is kept (|x| >= thr) and non-zero (-0.0 is zero)
+    const uint32_t tt = thr | (thr << 16);
+#pragma unroll
+    for (int j = 0; j < kD / 2; j++) {
+        const uint32_t keep = (w[j] - tt) >> 15;                      // guard bit survives iff magnitude >= thr
+        const uint32_t nz = ((w[j] & 0x7fff7fffu) + 0x7fff7fffu) >> 15;   // carry into the guard position iff magnitude != 0
+        w[j] = keep & nz & ONES;
     }
-    block_prefix_store(cnt, accum + h * rows.idx_stride + rows.tile0, tile, blk_total + (int64_t)h * gridDim.x + tb, &s_tot);
+    uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;   // masks of the lane's two tiles (MSB = element 0)
+    if (key) {
+        key_masks<0>(w, a_lo, a_hi, b_lo, b_hi);
+    } else {
+#pragma unroll
+        for (int j = 0; j < kD / 2; j++) {
+            const uint32_t two = ((w[j] << 1) | (w[j] >> 16)) & 3u;   // (element 2j, element 2j + 1)
+            const int e = 2 * (j & 31);                                // first of the two elements inside its tile
+            uint32_t& word = (j < 32) ? (e < 32 ? a_hi : a_lo) : (e < 32 ? b_hi : b_lo);
+            word |= two << (30 - (e & 31));
+        }
+    }
+    const uint64_t ma = ((uint64_t)a_hi << 32) | a_lo, mb = ((uint64_t)b_hi << 32) | b_lo;
+    int32_t ca = ((__popcll(ma) + 7) & ~7) >> 1, cb = ((__popcll(mb) + 7) & ~7) >> 1;   // compression.py:46-48
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {   // inclusive scans over the lanes
+        const int32_t ua = __shfl_up(ca, o), ub = __shfl_up(cb, o);
+        if (lane >= o) { ca += ua; cb += ub; }
+    }
+    const int32_t tot_a = __shfl(ca, 63);
+    int64_t* bmp_row = bmp + h * rows.bmp_stride + rows.tile0 + (int64_t)tb * kD;
+    int32_t* acc_row = accum + h * rows.idx_stride + rows.tile0 + (int64_t)tb * kD;
+    bmp_row[lane] = (int64_t)ma;
+    bmp_row[64 + lane] = (int64_t)mb;
+    acc_row[lane + 1] = ca;                  // prefix INSIDE the block; pass 2 adds the block's base
+    acc_row[64 + lane + 1] = tot_a + cb;
+    if (lane == 63) blk[(int64_t)h * ntb + tb] = tot_a + cb;
 }
 
-// K: tile (tb, d) = tokens tb*64..+63 of channel d (compression.py:32-36 on the transposed input); lane = token.
-// The 64x128 block is staged through LDS (row stride 65 dwords: conflict-free column reads).
+// ------------------------------------------------------------------------------------------------ scan
+// One workgroup per (head, side): block totals -> exclusive bases (torch.cumsum + cat, compression.py:294-298, at block
+// granularity; the prefix inside the blocks is already there).  Append mode (rows.tile0 > 0): the head's entry tile0
+// already holds the total of the tiles in use (model :352-360) and is the first base.  Also the head's new stream length
+// (compression.py:302) and, for a cache view, the check that it still fits the head's region.
+__global__ __launch_bounds__(kThreads) void block_scan_kernel(Side s0, Side s1, int ntb, int32_t* __restrict__ overflow)
+{
+    __shared__ int32_t s_wave[kWaves];
+    const bool z = blockIdx.y != 0;
+    int32_t* blk = z ? s1.blk : s0.blk;
+    int32_t* accum = z ? s1.accum : s0.accum;
+    int64_t* totals = z ? s1.totals : s0.totals;
+    const Rows rows = z ? s1.rows : s0.rows;
+    const int64_t region = z ? s1.region_halfs : s0.region_halfs;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* bt = blk + (int64_t)blockIdx.x * ntb;
+    int32_t* a = accum + (int64_t)blockIdx.x * rows.idx_stride + rows.tile0;
+    int32_t carry = rows.tile0 ? a[0] : 0;
+    for (int base = 0; base < ntb; base += kThreads) {
+        const int i = base + threadIdx.x;
+        const int32_t own = (i < ntb) ? bt[i] : 0;
+        int32_t v = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {   // inclusive scan inside the wave
+            const int32_t u = __shfl_up(v, o);
+            if (lane >= o) v += u;
+        }
+        if (lane == 63) s_wave[wave] = v;
+        __syncthreads();
+        int32_t add = carry;
+        for (int w = 0; w < wave; w++) add += s_wave[w];
+        const int32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (i < ntb) bt[i] = v - own + add;   // exclusive: the base of block i
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (rows.tile0 == 0) a[0] = 0;
+        totals[blockIdx.x] = 2 * (int64_t)carry;   // halfs in this head's stream (compression.py:302)
+        if (region > 0 && 2 * (int64_t)carry > region && overflow) atomicOr(overflow, 1);
+    }
+}
+
+// head_off[h] = exclusive prefix of totals (compression.py:303-304), head_off[B'] = grand total.  In place, one workgroup.
+__global__ __launch_bounds__(kThreads) void head_offsets_kernel(int64_t* __restrict__ head_off, int Bp)
+{
+    __shared__ int64_t s_wave[kWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t carry = 0;
+    for (int base = 0; base < Bp; base += kThreads) {
+        const int i = base + threadIdx.x;
+        const int64_t own = (i < Bp) ? head_off[i] : 0;
+        int64_t v = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t u = __shfl_up(v, o);
+            if (lane >= o) v += u;
+        }
+        if (lane == 63) s_wave[wave] = v;
+        __syncthreads();
+        int64_t add = carry;
+        for (int w = 0; w < wave; w++) add += s_wave[w];
+        const int64_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (i < Bp) head_off[i] = v - own + add;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) head_off[Bp] = carry;
+}
+
+// ------------------------------------------------------------------------------------------------ pack
+// Non-zeros of a tile in ascending element order at stream offset 2*accum[tile] (compression.py:164-174), then zeros up
+// to ceil8(nnz) (the reference relies on a pre-zeroed buffer, :309; here the wave writes them).  `m` = the tile's bitmap
+// as stored (MSB = element 0), wave-uniform; v = the lane's raw element.
+__device__ __forceinline__ void pack_tile(uint16_t* __restrict__ dst, uint64_t m, uint16_t v, int lane)
+{
+    const uint64_t mr = __builtin_bitreverse64(m);   // bit l <=> element l
+    const int nnz = __popcll(mr);
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mr, 0u));
+    if ((mr >> lane) & 1ull) dst[rank] = v;
+    const int padded = (nnz + 7) & ~7;
+    if (lane >= nnz && lane < padded) dst[lane] = 0;
+}
+
+// The 64x128 K block staged through LDS (row stride 65 dwords: conflict-free column reads).
 constexpr int kRowWords = kD / 2 + 1;
 
 __device__ __forceinline__ void load_block_transposable(uint32_t* s_blk, const uint16_t* __restrict__ xb)
@@ -175,190 +337,76 @@ __device__ __forceinline__ uint16_t block_elem(const uint32_t* s_blk, int token,
     return (uint16_t)((d & 1) ? (w >> 16) : (w & 0xffffu));
 }
 
-__global__ __launch_bounds__(kThreads) void bitmap_key_kernel(const uint16_t* __restrict__ x, int t, int64_t* __restrict__ bmp,
-                                                                int32_t* __restrict__ accum, int32_t* __restrict__ blk_total,
-                                                                Rows rows)
+// Pass 2.  grid: x = token block, y = head, z = side; 256 threads.  `overflow` set (a head outgrew its region of a cache
+// view) -> nothing is written: the caller re-houses the cache and repeats the append.
+__global__ __launch_bounds__(kThreads) void tile_pack_kernel(Side s0, Side s1, int ntb, const int32_t* __restrict__ overflow)
 {
     __shared__ uint32_t s_blk[64 * kRowWords];
     __shared__ uint64_t s_bmp[kD];
+    __shared__ int32_t s_start[kD];   // stream start of every tile of the block, half2 units, before the base is added
+    if (overflow && *overflow) return;
+    const bool z = blockIdx.z != 0;
+    const uint16_t* x = z ? s1.x : s0.x;
+    const int64_t head_stride = z ? s1.head_stride : s0.head_stride;
+    const int64_t* bmp = z ? s1.bmp : s0.bmp;
+    int32_t* accum = z ? s1.accum : s0.accum;
+    const int32_t* blk = z ? s1.blk : s0.blk;
+    const int64_t* head_off = z ? s1.head_off : s0.head_off;
+    const uint32_t* nz_offset = z ? s1.nz_offset : s0.nz_offset;
+    uint16_t* nz = z ? s1.nz : s0.nz;
+    const Rows rows = z ? s1.rows : s0.rows;
+    const int key = z ? s1.key : s0.key;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tb = blockIdx.x, h = blockIdx.y;
-    load_block_transposable(s_blk, x + ((int64_t)h * t + (int64_t)tb * 64) * kD);
-    __syncthreads();
-    for (int d = wave; d < kD; d += kWaves) {
-        const uint64_t m = __builtin_bitreverse64(__ballot(nonzero_h(block_elem(s_blk, lane, d))));
-        if (lane == 0) s_bmp[d] = m;
-    }
-    __syncthreads();
-    __shared__ int32_t s_tot;
-    int32_t cnt = 0;
-    const int64_t tile = (int64_t)tb * kD + (threadIdx.x & (kD - 1));
+    const uint16_t* xb = x + h * head_stride + (int64_t)tb * 64 * kD;
+    const int32_t base = blk ? blk[(int64_t)h * ntb + tb] : 0;
+    int32_t* acc_row = accum + (int64_t)h * rows.idx_stride + rows.tile0 + (int64_t)tb * kD;
+    if (key) load_block_transposable(s_blk, xb);
     if (threadIdx.x < kD) {
-        const uint64_t m = s_bmp[threadIdx.x];
-        bmp[h * rows.bmp_stride + rows.tile0 + tile] = (int64_t)m;
-        cnt = ((__popcll(m) + 7) & ~7) >> 1;
-    }
-    block_prefix_store(cnt, accum + h * rows.idx_stride + rows.tile0, tile, blk_total + (int64_t)h * gridDim.x + tb, &s_tot);
-}
-
-// ------------------------------------------------------------------------------------------------ scan
-// accum[h][0] = 0, accum[h][i+1] = sum of raw counts [0..i]  (torch.cumsum + cat, compression.py:294-298), in three
-// parallel pieces: the bitmap kernels leave the inclusive prefix INSIDE each 64-token block and the block totals;
-// block_scan_kernel (one workgroup per head) turns the totals into every block's base; block_fixup_kernel (one
-// workgroup per block) adds the base.  Append mode (rows.tile0 > 0): the head's entry tile0 already holds the total of
-// the tiles in use (model :352-360) and is the first base.
-__global__ __launch_bounds__(kThreads) void block_scan_kernel(int32_t* __restrict__ blk_total, int ntb,
-                                                              int32_t* __restrict__ accum, int64_t* __restrict__ totals,
-                                                              Rows rows)
-{
-    __shared__ int32_t s_wave[kWaves];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t* bt = blk_total + (int64_t)blockIdx.x * ntb;
-    int32_t* a = accum + (int64_t)blockIdx.x * rows.idx_stride + rows.tile0;
-    int32_t carry = rows.tile0 ? a[0] : 0;
-    for (int base = 0; base < ntb; base += kThreads) {
-        const int i = base + threadIdx.x;
-        const int32_t own = (i < ntb) ? bt[i] : 0;
-        int32_t v = own;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {   // inclusive scan inside the wave
-            const int32_t u = __shfl_up(v, o);
-            if (lane >= o) v += u;
+        const int d = threadIdx.x;
+        s_bmp[d] = (uint64_t)bmp[h * rows.bmp_stride + rows.tile0 + (int64_t)tb * kD + d];
+        if (blk) {
+            const int32_t incl = acc_row[d + 1];      // block-local inclusive prefix left by pass 1
+            if (d + 1 < kD) s_start[d + 1] = incl;
+            if (d == 0) s_start[0] = 0;
+            acc_row[d + 1] = base + incl;              // the offsets of the format (exclusive prefix over the whole head)
+        } else {
+            s_start[d] = acc_row[d];                   // two-call form: the fix-up pass has already added the bases
         }
-        if (lane == 63) s_wave[wave] = v;
-        __syncthreads();
-        int32_t add = carry;
-        for (int w = 0; w < wave; w++) add += s_wave[w];
-        const int32_t blk = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        if (i < ntb) bt[i] = v - own + add;   // exclusive: the base of block i
-        carry += blk;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        if (rows.tile0 == 0) a[0] = 0;
-        totals[blockIdx.x] = 2 * (int64_t)carry;   // halfs in this head's stream (compression.py:302)
-    }
-}
-
-// grid: x = token block, y = head; 128 threads.
-__global__ __launch_bounds__(kD) void block_fixup_kernel(const int32_t* __restrict__ blk_base, int32_t* __restrict__ accum,
-                                                         Rows rows)
-{
-    const int tb = blockIdx.x, h = blockIdx.y;
-    const int32_t base = blk_base[(int64_t)h * gridDim.x + tb];
-    accum[h * rows.idx_stride + rows.tile0 + (int64_t)tb * kD + threadIdx.x + 1] += base;
-}
-
-// head_off[h] = exclusive prefix of totals (compression.py:303-304), head_off[B'] = grand total.  In place.
-__global__ void head_offsets_kernel(int64_t* __restrict__ head_off, int Bp)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int64_t run = 0;
-        for (int h = 0; h < Bp; h++) {
-            const int64_t tot = head_off[h];
-            head_off[h] = run;
-            run += tot;
-        }
-        head_off[Bp] = run;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ pack
-// Non-zeros of a tile in ascending element order at stream offset 2*accum[tile] (compression.py:164-174),
-// then zeros up to ceil8(nnz) (the reference relies on a pre-zeroed buffer, :309; here the wave writes them).
-__device__ __forceinline__ void pack_tile(uint16_t* __restrict__ dst, uint16_t v, int lane)
-{
-    const uint64_t m = __ballot(nonzero_h(v));   // bit l <=> element l
-    const int nnz = __popcll(m);
-    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if ((m >> lane) & 1ull) dst[rank] = v;
-    const int padded = (nnz + 7) & ~7;
-    if (lane >= nnz && lane < padded) dst[lane] = 0;
-}
-
-// Start of head h's stream in halfs: head_off[h] (fresh result tensor) or 8 * nz_offset[h] (cache view).
-__device__ __forceinline__ int64_t head_base(const int64_t* __restrict__ head_off, const uint32_t* __restrict__ nz_offset, int h)
-{
-    return head_off ? head_off[h] : 8 * (int64_t)nz_offset[h];
-}
-
-__global__ __launch_bounds__(kThreads) void pack_value_kernel(const uint16_t* __restrict__ x, int t,
-                                                              const int32_t* __restrict__ accum,
-                                                              const int64_t* __restrict__ head_off,
-                                                              const uint32_t* __restrict__ nz_offset,
-                                                              uint16_t* __restrict__ nz, Rows rows)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tb = blockIdx.x, h = blockIdx.y;
-    const uint16_t* xb = x + ((int64_t)h * t + (int64_t)tb * 64) * kD;
-    const int32_t* acc = accum + (int64_t)h * rows.idx_stride + rows.tile0 + (int64_t)tb * kD;
-    uint16_t* nz_h = nz + head_base(head_off, nz_offset, h);
-    for (int r = wave; r < 64; r += kWaves) {
-        pack_tile(nz_h + 2 * (int64_t)acc[r], xb[r * kD + lane], lane);
-        pack_tile(nz_h + 2 * (int64_t)acc[64 + r], xb[r * kD + 64 + lane], lane);
-    }
-}
-
-__global__ __launch_bounds__(kThreads) void pack_key_kernel(const uint16_t* __restrict__ x, int t,
-                                                            const int32_t* __restrict__ accum,
-                                                            const int64_t* __restrict__ head_off,
-                                                            const uint32_t* __restrict__ nz_offset,
-                                                            uint16_t* __restrict__ nz, Rows rows)
-{
-    __shared__ uint32_t s_blk[64 * kRowWords];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tb = blockIdx.x, h = blockIdx.y;
-    load_block_transposable(s_blk, x + ((int64_t)h * t + (int64_t)tb * 64) * kD);
     __syncthreads();
-    const int32_t* acc = accum + (int64_t)h * rows.idx_stride + rows.tile0 + (int64_t)tb * kD;
-    uint16_t* nz_h = nz + head_base(head_off, nz_offset, h);
-    for (int d = wave; d < kD; d += kWaves)
-        pack_tile(nz_h + 2 * (int64_t)acc[d], block_elem(s_blk, lane, d), lane);
-}
-
-int bitmap_common(bool key, void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
-                  int64_t* totals, Rows rows, bool exclusive_prefix)
-{
-    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || !totals) return MUSTAFAR_EINVAL;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int ntb = t / 64;
-    const dim3 grid(ntb, Bp);
-    auto xs = static_cast<const uint16_t*>(x);
-    // block totals / bases [B'][ntb]: stream-ordered scratch, freed behind the last kernel that reads it
-    int32_t* blk = nullptr;
-    bool pooled = true;
-    if (hipMallocAsync(reinterpret_cast<void**>(&blk), sizeof(int32_t) * (size_t)Bp * ntb, st) != hipSuccess) {
-        (void)hipGetLastError();   // no stream-ordered allocator here: plain allocation, freed after the stream drains
-        pooled = false;
-        if (hipMalloc(reinterpret_cast<void**>(&blk), sizeof(int32_t) * (size_t)Bp * ntb) != hipSuccess) return (int)hipGetLastError();
-    }
-    if (key) bitmap_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, blk, rows);
-    else     bitmap_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, bmp, accum, blk, rows);
-    block_scan_kernel<<<Bp, kThreads, 0, st>>>(blk, ntb, accum, totals, rows);
-    block_fixup_kernel<<<grid, kD, 0, st>>>(blk, accum, rows);
-    if (exclusive_prefix) head_offsets_kernel<<<1, 64, 0, st>>>(totals, Bp);
-    const int err = (int)hipGetLastError();
-    if (pooled) {
-        (void)hipFreeAsync(blk, st);
+    uint16_t* nz_h = nz + (head_off ? head_off[h] : 8 * (int64_t)nz_offset[h]);
+    if (key) {
+        for (int d = wave; d < kD; d += kWaves)
+            pack_tile(nz_h + 2 * (int64_t)(base + s_start[d]), s_bmp[d], block_elem(s_blk, lane, d), lane);
     } else {
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(blk);
+        for (int r = wave; r < 64; r += kWaves) {
+            pack_tile(nz_h + 2 * (int64_t)(base + s_start[r]), s_bmp[r], xb[r * kD + lane], lane);
+            pack_tile(nz_h + 2 * (int64_t)(base + s_start[64 + r]), s_bmp[64 + r], xb[r * kD + 64 + lane], lane);
+        }
     }
-    return err;
 }
 
-int pack_common(bool key, void* stream, const void* x, int Bp, int t, int D, const int32_t* accum,
-                const int64_t* head_off, const uint32_t* nz_offset, void* nz_flat, Rows rows)
+// Move the rows [drop, len) of every head's window to the front (model :392-393 slices and clones; here in place).
+// One workgroup per (head, side); the rows that stay are read in full before any is written, so the ranges may overlap.
+__global__ __launch_bounds__(kThreads) void window_drop_front_kernel(uint16_t* k_win, uint16_t* v_win, int64_t head_stride, int len, int drop)
 {
-    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !accum || (!head_off && !nz_offset)) return MUSTAFAR_EINVAL;
-    if (!nz_flat) return 0;   // nothing to write: every tile of every head is empty
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(t / 64, Bp);
-    auto xs = static_cast<const uint16_t*>(x);
-    auto nz = static_cast<uint16_t*>(nz_flat);
-    if (key) pack_key_kernel<<<grid, kThreads, 0, st>>>(xs, t, accum, head_off, nz_offset, nz, rows);
-    else     pack_value_kernel<<<grid, kThreads, 0, st>>>(xs, t, accum, head_off, nz_offset, nz, rows);
-    return (int)hipGetLastError();
+    uint16_t* win = (blockIdx.y ? v_win : k_win) + blockIdx.x * head_stride;
+    const int n16 = (len - drop) * (kD / 8);   // 16-byte pieces to move (<= 4 per thread: checked on the host)
+    const uint4* src = reinterpret_cast<const uint4*>(win + (int64_t)drop * kD);
+    uint4* dst = reinterpret_cast<uint4*>(win);
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = threadIdx.x + i * kThreads;
+        if (p < n16) v[i] = src[p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = threadIdx.x + i * kThreads;
+        if (p < n16) dst[p] = v[i];
+    }
 }
 
 inline Rows fresh_rows(int t) { const int64_t tiles = (int64_t)t * kD / 64; return Rows{tiles, tiles + 1, 0}; }
@@ -371,6 +419,75 @@ inline bool view_rows(const mustafar_cache_view* v, int old_tokens, int t, Rows&
     rows = Rows{v->bmp_head_stride ? v->bmp_head_stride : tiles, v->idx_head_stride ? v->idx_head_stride : tiles + 1,
                 (int64_t)old_tokens * kD / 64};
     return rows.bmp_stride >= tiles && rows.idx_stride >= tiles + 1;
+}
+
+// Pass 1 (+ scan) of one or two sides.  `blk`: [sides][B'][ntb] ints of scratch.
+int launch_meta(hipStream_t st, Side* s, int sides, int Bp, int t, int32_t* blk, int32_t* overflow, bool exclusive_prefix)
+{
+    const int ntb = t / 64;
+    for (int i = 0; i < sides; i++) s[i].blk = blk + (int64_t)i * Bp * ntb;
+    const Side& s1 = s[sides - 1];
+    tile_meta_kernel<<<dim3(ntb, Bp, sides), 64, 0, st>>>(s[0], s1, ntb);
+    block_scan_kernel<<<dim3(Bp, sides), kThreads, 0, st>>>(s[0], s1, ntb, overflow);
+    if (exclusive_prefix)
+        for (int i = 0; i < sides; i++) head_offsets_kernel<<<1, kThreads, 0, st>>>(s[i].totals, Bp);
+    return (int)hipGetLastError();
+}
+
+int launch_pack(hipStream_t st, const Side* s, int sides, int Bp, int t, const int32_t* overflow)
+{
+    tile_pack_kernel<<<dim3(t / 64, Bp, sides), kThreads, 0, st>>>(s[0], s[sides - 1], t / 64, overflow);
+    return (int)hipGetLastError();
+}
+
+// grid: x = token block, y = head; 128 threads.  Two-call form only (mustafar_compress_bitmap_* must leave complete
+// offsets behind: the caller sizes the packed buffer between the calls); the fused form adds the bases in pass 2.
+__global__ __launch_bounds__(kD) void block_fixup_kernel(const int32_t* __restrict__ blk_base, int32_t* __restrict__ accum,
+                                                         Rows rows)
+{
+    const int tb = blockIdx.x, h = blockIdx.y;
+    const int32_t base = blk_base[(int64_t)h * gridDim.x + tb];
+    accum[h * rows.idx_stride + rows.tile0 + (int64_t)tb * kD + threadIdx.x + 1] += base;
+}
+
+int bitmap_common(bool key, void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
+                  int64_t* totals, Rows rows, bool exclusive_prefix)
+{
+    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || !totals) return MUSTAFAR_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ntb = t / 64;
+    // block totals / bases [B'][ntb]: stream-ordered scratch, freed behind the last kernel that reads it
+    int32_t* blk = nullptr;
+    bool pooled = true;
+    if (hipMallocAsync(reinterpret_cast<void**>(&blk), sizeof(int32_t) * (size_t)Bp * ntb, st) != hipSuccess) {
+        (void)hipGetLastError();   // no stream-ordered allocator here: plain allocation, freed after the stream drains
+        pooled = false;
+        if (hipMalloc(reinterpret_cast<void**>(&blk), sizeof(int32_t) * (size_t)Bp * ntb) != hipSuccess) return (int)hipGetLastError();
+    }
+    Side s{static_cast<const uint16_t*>(x), (int64_t)t * kD, bmp, accum, nullptr, totals, nullptr, nullptr, nullptr, rows, 0, 0, key ? 1 : 0};
+    int err = launch_meta(st, &s, 1, Bp, t, blk, nullptr, false);
+    if (!err) {
+        block_fixup_kernel<<<dim3(ntb, Bp), kD, 0, st>>>(blk, accum, rows);
+        if (exclusive_prefix) head_offsets_kernel<<<1, kThreads, 0, st>>>(totals, Bp);
+        err = (int)hipGetLastError();
+    }
+    if (pooled) {
+        (void)hipFreeAsync(blk, st);
+    } else {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(blk);
+    }
+    return err;
+}
+
+int pack_common(bool key, void* stream, const void* x, int Bp, int t, int D, const int64_t* bmp, const int32_t* accum,
+                const int64_t* head_off, const uint32_t* nz_offset, void* nz_flat, Rows rows)
+{
+    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || (!head_off && !nz_offset)) return MUSTAFAR_EINVAL;
+    if (!nz_flat) return 0;   // nothing to write: every tile of every head is empty
+    Side s{static_cast<const uint16_t*>(x), (int64_t)t * kD, const_cast<int64_t*>(bmp), const_cast<int32_t*>(accum), nullptr, nullptr,
+           head_off, nz_offset, static_cast<uint16_t*>(nz_flat), rows, 0, 0, key ? 1 : 0};
+    return launch_pack(static_cast<hipStream_t>(stream), &s, 1, Bp, t, nullptr);
 }
 
 }  // namespace
@@ -396,13 +513,13 @@ int mustafar_compress_bitmap_value(void* stream, const void* x, int Bp, int t, i
                                    int64_t* head_off)
 { return bitmap_common(false, stream, x, Bp, t, D, bmp, accum, head_off, fresh_rows(t), true); }
 
-int mustafar_compress_pack_key(void* stream, const void* x, int Bp, int t, int D, const int64_t* /*bmp*/,
+int mustafar_compress_pack_key(void* stream, const void* x, int Bp, int t, int D, const int64_t* bmp,
                                const int32_t* accum, const int64_t* head_off, void* nz_flat)
-{ return pack_common(true, stream, x, Bp, t, D, accum, head_off, nullptr, nz_flat, fresh_rows(t)); }
+{ return pack_common(true, stream, x, Bp, t, D, bmp, accum, head_off, nullptr, nz_flat, fresh_rows(t)); }
 
-int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int D, const int64_t* /*bmp*/,
+int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int D, const int64_t* bmp,
                                  const int32_t* accum, const int64_t* head_off, void* nz_flat)
-{ return pack_common(false, stream, x, Bp, t, D, accum, head_off, nullptr, nz_flat, fresh_rows(t)); }
+{ return pack_common(false, stream, x, Bp, t, D, bmp, accum, head_off, nullptr, nz_flat, fresh_rows(t)); }
 
 // ---- in-place append into a cache view (model :339-390 without the re-copies) ----------------------------------------
 int mustafar_cache_append_bitmap_key(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
@@ -428,7 +545,8 @@ int mustafar_cache_append_pack_key(void* stream, const void* x, int Bp, int t, i
 {
     Rows rows;
     if (!view_rows(dst, old_tokens, t, rows) || !dst->nz) return MUSTAFAR_EINVAL;
-    return pack_common(true, stream, x, Bp, t, D, reinterpret_cast<const int32_t*>(dst->idx), nullptr, dst->nz_offset, dst->nz, rows);
+    return pack_common(true, stream, x, Bp, t, D, reinterpret_cast<const int64_t*>(dst->bmp), reinterpret_cast<const int32_t*>(dst->idx), nullptr,
+                       dst->nz_offset, dst->nz, rows);
 }
 
 int mustafar_cache_append_pack_value(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
@@ -436,7 +554,47 @@ int mustafar_cache_append_pack_value(void* stream, const void* x, int Bp, int t,
 {
     Rows rows;
     if (!view_rows(dst, old_tokens, t, rows) || !dst->nz) return MUSTAFAR_EINVAL;
-    return pack_common(false, stream, x, Bp, t, D, reinterpret_cast<const int32_t*>(dst->idx), nullptr, dst->nz_offset, dst->nz, rows);
+    return pack_common(false, stream, x, Bp, t, D, reinterpret_cast<const int64_t*>(dst->bmp), reinterpret_cast<const int32_t*>(dst->idx), nullptr,
+                       dst->nz_offset, dst->nz, rows);
+}
+
+// ---- fused forms (one launch per pass for K and V together; no allocation, no host read: graph-capturable) ----------
+int64_t mustafar_compress_scratch_bytes(int Bp, int t)
+{
+    if (Bp < 1 || t < 64 || (t & 63)) return 0;
+    return 2 * (int64_t)Bp * (t / 64) * (int64_t)sizeof(int32_t);
+}
+
+int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int64_t head_stride, int Bp, int t, int D, int kth_k,
+                             int kth_v, const mustafar_cache_view* k_dst, const mustafar_cache_view* v_dst, int old_tokens,
+                             int64_t* k_head_total, int64_t* v_head_total, int64_t k_region_halfs, int64_t v_region_halfs,
+                             int32_t* overflow_flag, void* scratch)
+{
+    Rows kr, vr;
+    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !k_x || !v_x || head_stride < (int64_t)t * kD || kth_k < 0 || kth_k > kD ||
+        kth_v < 0 || kth_v > kD || !k_head_total || !v_head_total || !scratch || !view_rows(k_dst, old_tokens, t, kr) ||
+        !view_rows(v_dst, old_tokens, t, vr) || !k_dst->nz || !v_dst->nz)
+        return MUSTAFAR_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Side s[2] = {
+        {static_cast<const uint16_t*>(k_x), head_stride, reinterpret_cast<int64_t*>(k_dst->bmp), reinterpret_cast<int32_t*>(k_dst->idx), nullptr,
+         k_head_total, nullptr, k_dst->nz_offset, static_cast<uint16_t*>(k_dst->nz), kr, k_region_halfs, kth_k, 1},
+        {static_cast<const uint16_t*>(v_x), head_stride, reinterpret_cast<int64_t*>(v_dst->bmp), reinterpret_cast<int32_t*>(v_dst->idx), nullptr,
+         v_head_total, nullptr, v_dst->nz_offset, static_cast<uint16_t*>(v_dst->nz), vr, v_region_halfs, kth_v, 0}};
+    const int err = launch_meta(st, s, 2, Bp, t, static_cast<int32_t*>(scratch), overflow_flag, false);
+    if (err) return err;
+    return launch_pack(st, s, 2, Bp, t, overflow_flag);
+}
+
+int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int64_t head_stride, int Bp, int len, int drop)
+{
+    if (!k_window || !v_window || Bp < 1 || drop < 0 || len < drop || head_stride < (int64_t)len * kD ||
+        (int64_t)(len - drop) * (kD / 8) > 4 * kThreads)   // at most 64 rows stay (the hook keeps residual_length = 32)
+        return MUSTAFAR_EINVAL;
+    if (len == drop || drop == 0) return 0;
+    window_drop_front_kernel<<<dim3(Bp, 2), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<uint16_t*>(k_window), static_cast<uint16_t*>(v_window), head_stride, len, drop);
+    return (int)hipGetLastError();
 }
 
 }  // extern "C"

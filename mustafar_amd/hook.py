@@ -131,6 +131,22 @@ class Window:
         self.len -= n
         self.buf[:, :, :self.len] = keep
 
+    @staticmethod
+    def drop_front_pair(k_w: "Window", v_w: "Window", n: int):
+        """Slide both windows by n rows with one launch (at most 64 rows stay: the hook keeps residual_length of them)."""
+        keep = k_w.len - n
+        if v_w.len != k_w.len or k_w.buf.shape != v_w.buf.shape or keep > 64 or not k_w.buf.is_cuda:
+            k_w.drop_front(n)
+            v_w.drop_front(n)
+            return
+        L = _lib.load()
+        B, H, cap, D = k_w.buf.shape
+        with torch.cuda.device(k_w.buf.device):
+            err = L.mustafar_window_drop_front(torch.cuda.current_stream(k_w.buf.device).cuda_stream, k_w.buf.data_ptr(), v_w.buf.data_ptr(),
+                                               cap * D, B * H, k_w.len, n)
+        _lib.check(err, "mustafar_window_drop_front")
+        k_w.len = v_w.len = keep
+
     def clone(self) -> "Window":
         w = Window.__new__(Window)
         w.buf, w.len = self.buf.clone(), self.len
@@ -167,7 +183,14 @@ class MustafarAttention:
         total_batch_kv = bsz * self.num_key_value_heads
         # :416 computes ((L - R)//256)*256, which is -256 for L < R; clamp at 0.
         compressed_length = max(0, ((kv_seq_len - self.cfg.residual_length) // 256) * 256)
-        if compressed_length != 0:
+        if compressed_length != 0 and self.cfg.arena and self.cfg.api == "fused" and key_states.is_contiguous() and value_states.is_contiguous():
+            # straight from the raw K / V into appendable storage: prune thresholds in registers, no pruned copy (:419-434)
+            k_compressed, v_compressed = CompressedArena.from_raw_pair(
+                key_states, value_states, compressed_length, compression.kth_from_sparsity(self.cfg.k_sparsity, D),
+                compression.kth_from_sparsity(self.cfg.v_sparsity, D), compressed_length + self.cfg.arena_extra_tokens, self.cfg.arena_headroom)
+            k_local_window = key_states[:, :, compressed_length:, :].clone().contiguous()             # :427
+            v_local_window = value_states[:, :, compressed_length:, :].clone().contiguous()           # :435
+        elif compressed_length != 0:
             k_pruned = self.dh_prune_key(key_states[:, :, :compressed_length, :])                     # :419
             v_pruned = self.dh_prune_value(value_states[:, :, :compressed_length, :])                 # :420
             if self.cfg.arena and self.cfg.api == "fused":   # straight into appendable storage
@@ -281,24 +304,27 @@ class MustafarAttention:
             return out, (k_c, k_w, v_c, v_w, C, kv_seq_len - 1)   # lengths advance with the device counter
         k_w.len = v_w.len = w_len
         if (kv_seq_len - cfg.residual_length - C) % 256 == 0 and w_len >= 256:                          # :324
-            k_blk = self.dh_prune_key(k_w.buf[:, :, :256, :]).reshape(Bkv, -1, D)                       # :325
-            v_blk = self.dh_prune_value(v_w.buf[:, :, :256, :]).reshape(Bkv, -1, D)                     # :326
+            kth_k = compression.kth_from_sparsity(cfg.k_sparsity, D)
+            kth_v = compression.kth_from_sparsity(cfg.v_sparsity, D)
             if use_arena or (cfg.arena and C == 0):
+                # prune (:325-326) + compress + append (:328-390) of the raw window rows in three launches, no host read
                 if C == 0:
-                    k_c = CompressedArena.from_pruned(k_blk, "key", 256 + cfg.arena_extra_tokens, cfg.arena_headroom)
-                    v_c = CompressedArena.from_pruned(v_blk, "value", 256 + cfg.arena_extra_tokens, cfg.arena_headroom)
+                    k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, 256 + cfg.arena_extra_tokens,
+                                                             cfg.arena_headroom)
                 else:
-                    k_c.append(k_blk)                                                                   # :339-390, in place
-                    v_c.append(v_blk)
+                    CompressedArena.append_window_pair(k_c, v_c, k_w.buf, v_w.buf, 256, kth_k, kth_v)
+                Window.drop_front_pair(k_w, v_w, 256)                                                   # :392-393, in place
             else:
+                k_blk = self.dh_prune_key(k_w.buf[:, :, :256, :]).reshape(Bkv, -1, D)                   # :325
+                v_blk = self.dh_prune_value(v_w.buf[:, :, :256, :]).reshape(Bkv, -1, D)                 # :326
                 k_new, v_new = _compress(k_blk, "key"), _compress(v_blk, "value")                       # :328-337
                 if C == 0:
                     k_c, v_c = k_new, v_new
                 else:
                     k_c = append_compressed(k_c, k_new, Bkv, C, 256, D)
                     v_c = append_compressed(v_c, v_new, Bkv, C, 256, D)
-            k_w.drop_front(256)                                                                         # :392-393
-            v_w.drop_front(256)
+                k_w.drop_front(256)                                                                     # :392-393
+                v_w.drop_front(256)
             C += 256
         return out, (k_c, k_w, v_c, v_w, C, kv_seq_len)
 

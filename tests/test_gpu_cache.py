@@ -118,3 +118,90 @@ def test_view_argument_checks():
     assert L.mustafar_cache_append_bitmap_key(st, x.data_ptr(), 2, 256, 128, arena.view_ptr(), 128, tot.data_ptr()) == 1
     assert L.mustafar_cache_append_bitmap_key(st, x.data_ptr(), 2, 256, 128, arena.view_ptr(), 100, tot.data_ptr()) == 1   # % 64
     assert L.mustafar_cache_append_pack_key(st, x.data_ptr(), 2, 256, 128, None, 128) == 1
+
+
+# ---- fused forms: prune + compress + append of RAW rows of K and V together (mustafar_cache_append_kv) ----------------
+def _raw(B, H, rows, seed, special=False):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn((B, H, rows, 128), device=DEV, generator=g).half()
+    if special:   # ties at the threshold, signed zeros, an all-zero row, a constant row (everything ties: all 128 kept)
+        x[0, 0, 0, :] = 0
+        x[0, 0, 1, :] = 0.5
+        x[0, 0, 2, ::2] = x[0, 0, 2, 1::2]
+        x[0, 0, 3, :8] = -0.0
+        x[-1, -1, 5, :] = torch.tensor([1.0, -1.0] * 64, device=DEV).half()
+    return x
+
+
+def _oracle_pruned(x, s, t):
+    B, H, _, D = x.shape
+    return torch.from_numpy(orc.prune_magnitude(x[:, :, :t].contiguous().cpu().numpy(), s)).reshape(B * H, t, D)
+
+
+@pytest.mark.parametrize("s_k,s_v", [(0.7, 0.7), (0.5, 0.8)])
+def test_fused_prefill_from_raw_rows_matches_oracle_prune_and_compress(s_k, s_v):
+    """from_raw_pair reads RAW K/V [B, Hkv, L, 128] (head stride L * 128, only the first t tokens of every head) and must
+    equal oracle-prune + oracle-compress bit for bit -- thresholds, ties, signed zeros included."""
+    from mustafar_amd import compression
+    from mustafar_amd.cache import CompressedArena
+    B, H, L, t = 2, 3, 600, 512
+    K, V = _raw(B, H, L, 21, special=True), _raw(B, H, L, 22, special=True)
+    ka, va = CompressedArena.from_raw_pair(K, V, t, compression.kth_from_sparsity(s_k, 128), compression.kth_from_sparsity(s_v, 128))
+    assert ka.tokens == va.tokens == t
+    _assert_same_as_oracle(ka, _oracle_pruned(K, s_k, t), "key")
+    _assert_same_as_oracle(va, _oracle_pruned(V, s_v, t), "value")
+
+
+def test_fused_prefill_survives_an_underestimated_stream_region():
+    """Constant rows tie at the threshold, so every element is kept (model :107): twice the estimate.  The first attempt
+    raises the device-side overflow flag and packs nothing; the second attempt uses worst-case regions."""
+    from mustafar_amd.cache import CompressedArena
+    K = torch.full((1, 2, 256, 128), 0.25, device=DEV, dtype=torch.float16)
+    V = -K
+    ka, va = CompressedArena.from_raw_pair(K, V, 256, 89, 89)
+    assert int(ka.used.min()) == 256 * 128 and int(va.used.min()) == 256 * 128
+    _assert_same_as_oracle(ka, K.reshape(2, 256, 128), "key")
+    _assert_same_as_oracle(va, V.reshape(2, 256, 128), "value")
+
+
+def test_fused_trigger_append_from_a_window_buffer():
+    """The decode trigger (model :324-398): rows [0, 256) of window buffers with spare rows, appended behind 512 tokens,
+    twice (the second append sizes its room from the first one's asynchronously delivered stream lengths), then the slide."""
+    from mustafar_amd import compression
+    from mustafar_amd.cache import CompressedArena
+    from mustafar_amd.hook import Window
+    B, H, s = 2, 2, 0.7
+    kth = compression.kth_from_sparsity(s, 128)
+    K0, V0 = _raw(B, H, 512, 31), _raw(B, H, 512, 32)
+    ka, va = CompressedArena.from_raw_pair(K0, V0, 512, kth, kth, cap_tokens=768)
+    allK, allV = [_oracle_pruned(K0, s, 512)], [_oracle_pruned(V0, s, 512)]
+    for i in range(3):   # the third append outgrows the 768-token rows: re-housed, contents stay exact
+        kw, vw = Window(_raw(B, H, 288, 40 + i, special=(i == 1)), 352), Window(_raw(B, H, 288, 50 + i), 352)
+        keep_k, keep_v = kw.buf[:, :, 256:288].clone(), vw.buf[:, :, 256:288].clone()
+        allK.append(_oracle_pruned(kw.buf, s, 256))
+        allV.append(_oracle_pruned(vw.buf, s, 256))
+        CompressedArena.append_window_pair(ka, va, kw.buf, vw.buf, 256, kth, kth)
+        Window.drop_front_pair(kw, vw, 256)
+        assert kw.len == vw.len == 32
+        assert torch.equal(kw.view(), keep_k) and torch.equal(vw.view(), keep_v)
+    assert ka.tokens == va.tokens == 1280
+    _assert_same_as_oracle(ka, torch.cat(allK, 1), "key")
+    _assert_same_as_oracle(va, torch.cat(allV, 1), "value")
+
+
+def test_fused_append_equals_the_two_call_form():
+    """Same tokens through prune_magnitude + CompressedArena.append (the round-1 path, one host read per side) and through
+    append_window_pair: identical bytes in the arena."""
+    from mustafar_amd import compression
+    from mustafar_amd.cache import CompressedArena
+    B, H, s = 1, 4, 0.8
+    kth = compression.kth_from_sparsity(s, 128)
+    X0, X1 = _raw(B, H, 256, 61), _raw(B, H, 320, 62)
+    a_k, a_v = CompressedArena.from_raw_pair(X0, X0, 256, kth, kth, cap_tokens=1024)
+    CompressedArena.append_window_pair(a_k, a_v, X1, X1, 256, kth, kth)
+    for which, fused in (("key", a_k), ("value", a_v)):
+        b = CompressedArena.from_pruned(compression.prune_magnitude(X0.reshape(H, 256, 128), s), which, cap_tokens=1024)
+        b.append(compression.prune_magnitude(X1[:, :, :256].reshape(H, 256, 128).contiguous(), s))
+        fr, br = fused.to_reference(), b.to_reference()
+        assert torch.equal(fr[0], br[0]) and torch.equal(fr[1], br[1]) and torch.equal(fr[3], br[3])
+        assert torch.equal(torch.cat(fr[2]).view(torch.int16), torch.cat(br[2]).view(torch.int16))

@@ -34,4 +34,19 @@ for name in sys.argv[1:] or ["c3", "c4"]:
         res.update({f"{which}_bitmap_scan_us": round(t_b * 1e6, 1), f"{which}_bitmap_GBps": round((inb + bmp.numel() * 8 + acc.numel() * 4) / t_b / 1e9, 1),
                     f"{which}_pack_us": round(t_p * 1e6, 1), f"{which}_pack_GBps": round((inb + acc.numel() * 4 + total * 2) / t_p / 1e9, 1),
                     f"{which}_convert_call_us": round(t_full * 1e6, 1)})
+    # fused form: raw rows -> prune thresholds in registers -> bitmaps/offsets -> pack, K and V in the same three launches
+    from mustafar_amd.cache import CompressedArena
+    xk = torch.randn((batch, Hkv, T, 128), device=dev).half()
+    xv = torch.randn((batch, Hkv, T, 128), device=dev).half()
+    kth = compression.kth_from_sparsity(s, 128)
+    ka, va = CompressedArena.from_raw_pair(xk, xv, T, kth, kth)       # sizes the regions
+    scratch = torch.empty(int(L.mustafar_compress_scratch_bytes(Bp, T)), dtype=torch.uint8, device=dev)
+
+    def fused():
+        _lib.check(L.mustafar_cache_append_kv(st, xk.data_ptr(), xv.data_ptr(), T * 128, Bp, T, 128, kth, kth, ka.view_ptr(), va.view_ptr(), 0,
+                                              ka._totals.data_ptr(), va._totals.data_ptr(), ka.nz_cap, va.nz_cap, None, scratch.data_ptr()), "append_kv")
+    t_f = timeit(fused, 10)
+    out_b = int(ka.used.sum() + va.used.sum()) * 2 + 2 * Bp * tiles * 12
+    res.update(fused_prune_compress_kv_us=round(t_f * 1e6, 1), fused_per_side_us=round(t_f * 1e6 / 2, 1),
+               fused_GBps_in_twice_plus_out=round((2 * 2 * xk.numel() * 2 + out_b) / t_f / 1e9, 1))
     print(json.dumps(res), flush=True)
