@@ -136,6 +136,8 @@ typedef struct mustafar_cache_view {
     uint32_t* nz_offset;
     int64_t   bmp_head_stride;
     int64_t   idx_head_stride;
+    int64_t   nz_head_stride;   /* != 0: nz_offset[h] == h * nz_head_stride (uint4 units, < 2^32): the SpMV kernels then compute
+                                   the head's stream start instead of loading it (one memory latency less per wave) */
 } mustafar_cache_view;
 
 /* mustafar_decode_attention over two cache views (same semantics, same remaining arguments). */

@@ -17,7 +17,7 @@ _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 class CacheView(ctypes.Structure):
     """`mustafar_cache_view` of include/mustafar_hip.h: the four arrays of the compressed format + the head strides."""
     _fields_ = [("bmp", _vp), ("nz", _vp), ("idx", _vp), ("nz_offset", _vp),
-                ("bmp_head_stride", _i64), ("idx_head_stride", _i64)]
+                ("bmp_head_stride", _i64), ("idx_head_stride", _i64), ("nz_head_stride", _i64)]
 
 
 _view_p = ctypes.POINTER(CacheView)

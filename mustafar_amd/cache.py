@@ -13,6 +13,7 @@ read an arena through `mustafar_cache_view` (head strides), and `to_reference()`
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import torch
@@ -51,7 +52,8 @@ class CompressedArena:
         self._pending = None                                        # event behind an asynchronous copy of _totals into _host_totals
         self._overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._view = _lib.CacheView(self.bmp.data_ptr(), self.nz.data_ptr(), self.idx.data_ptr(), self.nz_offset.data_ptr(),
-                                    tiles, tiles + 1)
+                                    tiles, tiles + 1,
+                                    nz_cap // 8 if (self.heads * (nz_cap // 8) < 2 ** 32 and os.environ.get("MUSTAFAR_NZ_STRIDE", "1") != "0") else 0)
 
     @property
     def view(self) -> "_lib.CacheView":

@@ -712,12 +712,18 @@ __device__ __forceinline__ void value_window_wg(unsigned char* smem, const h16* 
 // grid: x = ceil(T/256) token super-blocks (SPLIT = 1: one wave per 64-token block) or ceil(T/128) (SPLIT = 2: two
 // waves per token block, 64 channels each, partial scores folded through LDS -- twice the workgroups, half as long:
 // used when the SPLIT = 1 grid would fit on the chip in a single round), y = kv-heads * (groups / G)
+#ifndef MUSTAFAR_KEY_WAVES      // experiment knob (tools/build_variant.sh): minimum waves per SIMD the key kernel is compiled for
+#define MUSTAFAR_KEY_BOUNDS __launch_bounds__(kThreads)
+#else
+#define MUSTAFAR_KEY_BOUNDS __launch_bounds__(kThreads, MUSTAFAR_KEY_WAVES)
+#endif
 template <int G, bool MF, int SPLIT>
-__global__ __launch_bounds__(kThreads) void key_spmv_kernel(
+__global__ MUSTAFAR_KEY_BOUNDS void key_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int N, int groups,
-    int ldc, WinArgs wa, int64_t bmp_stride, int64_t idx_stride)
-{   // ldc: row stride of `out` in halfs (T for the reference layout); bmp_stride / idx_stride: elements between the heads'
+    int ldc, WinArgs wa, int64_t bmp_stride, int64_t idx_stride, uint32_t nz_stride)
+{   // nz_stride != 0: head h's stream starts at uint4 index h * nz_stride (an arena: no load of nz_off in the wave's start-up chain)
+    // ldc: row stride of `out` in halfs (T for the reference layout); bmp_stride / idx_stride: elements between the heads'
     // rows of `bmp` / `idx` (0 = the reference's contiguous layout, 2T and 2T + 1; larger for an arena with spare capacity)
     constexpr int kTabBytes = (MF && G == 4) ? 4 * kKeyTabStride : 0;   // MFMA engine: q rows of the 4 heads
     __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(kThreads) void key_spmv_kernel(
 
     const uint64_t* bmp_t = bmp + (int64_t)kvh * (bmp_stride ? bmp_stride : tiles) + (int64_t)tb * kTilesPerTb;
     const uint32_t* idx_t = idx + (int64_t)kvh * (idx_stride ? idx_stride : tiles + 1) + (int64_t)tb * kTilesPerTb;
-    const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
+    const unsigned char* nz_h = nz + 16ull * (nz_stride ? (uint64_t)kvh * nz_stride : (uint64_t)nz_off[kvh]);
     const uint32_t chead = (uint32_t)N * (kD / 2);
 
     uint32_t rows = 1u;   // bit n: row n has to be computed
@@ -923,12 +929,17 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
 // wave does.
 //   direct != 0 (one chunk): fp16 results go straight to `out`;
 //   else fp32 partial slabs ws[(s*BH + bh)*N + n][128] + one row mask per workgroup in `flags`.
+#ifndef MUSTAFAR_VALUE_MF_WAVES   // experiment knob (tools/build_variant.sh): minimum waves per SIMD of the matrix-pipe value kernels
+#define MUSTAFAR_VALUE_BOUNDS __launch_bounds__(NW * 64)
+#else
+#define MUSTAFAR_VALUE_BOUNDS __launch_bounds__(NW * 64, MF ? MUSTAFAR_VALUE_MF_WAVES : 1)
+#endif
 template <int G, bool MF, int NW, int SPLIT>
-__global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
+__global__ MUSTAFAR_VALUE_BOUNDS void value_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
     uint32_t* __restrict__ flags, int T, int N, int groups, int BH, int tb_per_wg, int direct, int ldb, WinArgs wa,
-    int64_t bmp_stride, int64_t idx_stride)
+    int64_t bmp_stride, int64_t idx_stride, uint32_t nz_stride)
 {   // bmp_stride / idx_stride: as in key_spmv_kernel;  ldb: row stride of `p` in halfs (T for the reference layout; must be even, % 8 == 0 for the MFMA engine)
     constexpr int kTabBytes = (MF && G == 4) ? NW * 4 * kValTabStride : 0;
     constexpr int kStride = NW / SPLIT;   // token blocks in flight per workgroup
@@ -958,7 +969,7 @@ __global__ __launch_bounds__(NW * 64) void value_spmv_kernel(
 
     const uint64_t* bmp_h = bmp + (int64_t)kvh * (bmp_stride ? bmp_stride : tiles);
     const uint32_t* idx_h = idx + (int64_t)kvh * (idx_stride ? idx_stride : tiles + 1);
-    const unsigned char* nz_h = nz + 16ull * nz_off[kvh];
+    const unsigned char* nz_h = nz + 16ull * (nz_stride ? (uint64_t)kvh * nz_stride : (uint64_t)nz_off[kvh]);
     float* red = reinterpret_cast<float*>(smem);   // [NW][2*G][64], overlays the stage windows
     float* ws_slab = ws + (int64_t)blockIdx.x * BH * N * kD;
     const uint32_t chead = (uint32_t)N * ((uint32_t)ldb / 2u);
@@ -1316,6 +1327,7 @@ inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0)
 // FMA engine of the G = 4 kernels: 0 = VALU (v_fma_mix_f32; default, MFMA left off as the north_star asks),
 // 1 = matrix pipe as a 4-wide FMA unit (v_mfma_f32_4x4x4_16B_f16; opt-in: MUSTAFAR_FMA_ENGINE=mfma or
 // mustafar_set_fma_engine(1)).
+inline int fma_engine();
 int g_key_split = -1;   // 0 = automatic; MUSTAFAR_KEY_SPLIT=1|2 forces
 inline int key_split(int ntb, int gy)
 {
@@ -1324,6 +1336,7 @@ inline int key_split(int ntb, int gy)
         g_key_split = e ? atoi(e) : 0;
     }
     if (g_key_split == 1 || g_key_split == 2) return g_key_split;
+    if (fma_engine()) return 1;   // matrix-pipe engine: one wave per block at every size (tools/sweep_forms.sh: c3 19.1 vs 20.2 us, c5 57 vs 65)
     // One wave per token block unless that grid is small (<= 2048 workgroups; the chip holds 256 CUs x 6 of them, see
     // tools/wave_trace.py): then a wave's latency chain, not throughput, sets the time, and two waves per block halve it.
     return ((int64_t)((ntb + kWaves - 1) / kWaves) * gy <= 2048) ? 2 : 1;
@@ -1376,7 +1389,7 @@ struct Profile {
 void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx, const uint32_t* nz_off,
                 const h16* q, h16* out, int T, int N, int groups, int Batch_Size, int ldc, WinArgs wa = WinArgs{},
                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,   // ev0/ev1: the kernel's own start / stop timestamps
-                int64_t bmp_stride = 0, int64_t idx_stride = 0)
+                int64_t bmp_stride = 0, int64_t idx_stride = 0, uint32_t nz_stride = 0)
 {
     const int G = pick_g(groups);
     const int gy = (Batch_Size / groups) * (groups / G);
@@ -1393,9 +1406,9 @@ void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, co
 #define MUSTAFAR_LK(GG, MFF)                                                                                                   \
     do {                                                                                                                       \
         if (split == 2) hipExtLaunchKernelGGL((key_spmv_kernel<GG, MFF, 2>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,         \
-                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa, bmp_stride, idx_stride);   \
+                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa, bmp_stride, idx_stride, nz_stride);   \
         else            hipExtLaunchKernelGGL((key_spmv_kernel<GG, MFF, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,         \
-                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa, bmp_stride, idx_stride);   \
+                                              bmp, nz, idx, nz_off, q, out, T, N, groups, ldc, wa, bmp_stride, idx_stride, nz_stride);   \
     } while (0)
     switch (G) {
         case 4:
@@ -1427,7 +1440,7 @@ inline int value_tb_stride() { return value_split() == 2 ? kValueWaves / 2 : kWa
 void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx,
                   const uint32_t* nz_off, const h16* p, h16* out, float* ws, uint32_t* flags, int T, int N, int groups,
                   int Batch_Size, int tb_per_wg, int direct, int ldb, WinArgs wa = WinArgs{}, hipEvent_t ev0 = nullptr,
-                  hipEvent_t ev1 = nullptr, int64_t bmp_stride = 0, int64_t idx_stride = 0)
+                  hipEvent_t ev1 = nullptr, int64_t bmp_stride = 0, int64_t idx_stride = 0, uint32_t nz_stride = 0)
 {
     const int G = pick_g(groups);
     if (wa.win) {   // window workgroups first; their partial slabs follow the grid.x token-chunk slabs
@@ -1440,10 +1453,10 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
     do {                                                                                                                       \
         if (value_split() == 2)                                                                                                \
             hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kValueWaves, 2>), grid, dim3(kValueWaves * 64), 0, st, ev0, ev1, 0, \
-                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride); \
+                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride); \
         else                                                                                                                   \
             hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kWaves, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,           \
-                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride); \
+                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride); \
     } while (0)
     switch (G) {
         case 4:
@@ -1589,7 +1602,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
         const WinArgs kw = ride_k ? WinArgs{kwin, knew, window_len_extra, window_len, window_capacity, 0, 0} : WinArgs{};
         launch_key(st, kc.bmp, static_cast<const unsigned char*>(kc.nz), kc.idx, kc.nz_offset, qh, sc, T, 1, groups, Batch_Size, ld_scores, kw,
                    prof ? g_prof.ev[4 * g_prof.n] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr, kc.bmp_head_stride,
-                   kc.idx_head_stride);
+                   kc.idx_head_stride, (uint32_t)kc.nz_head_stride);
     }
     const float inv_sqrt_d = (float)(1.0 / (double)sqrt_d);
     if (long_rows) {
@@ -1614,7 +1627,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
         if (ride_v) nwin_slabs = (window_capacity + kValueWinChunk - 1) / kValueWinChunk;
         launch_value(st, gv, vc.bmp, nz, vc.idx, vc.nz_offset, sc, no_out, ws, no_flags, T, 1, groups, Batch_Size, tb_per_wg, 0, ld_scores, vw,
                      prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr, prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, vc.bmp_head_stride,
-                     vc.idx_head_stride);
+                     vc.idx_head_stride, (uint32_t)vc.nz_head_stride);
         if (prof) g_prof.n++;
     }
     value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S + nwin_slabs, sc, ld_scores, T, ride_v ? nullptr : vwin, ride_v ? nullptr : vnew,
@@ -1635,9 +1648,9 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
                               int heads_per_mask_row)
 {
     const mustafar_cache_view kc{const_cast<uint64_t*>(k_bmp), const_cast<void*>(k_nz), const_cast<uint32_t*>(k_idx),
-                                 const_cast<uint32_t*>(k_nz_offset), 0, 0};
+                                 const_cast<uint32_t*>(k_nz_offset), 0, 0, 0};
     const mustafar_cache_view vc{const_cast<uint64_t*>(v_bmp), const_cast<void*>(v_nz), const_cast<uint32_t*>(v_idx),
-                                 const_cast<uint32_t*>(v_nz_offset), 0, 0};
+                                 const_cast<uint32_t*>(v_nz_offset), 0, 0, 0};
     return decode_attention(stream, kc, vc, q, k_window, v_window, k_new, v_new, window_len, window_capacity, scores, ld_scores, out,
                             workspace, Split_K, T, Batch_Size, num_key_value_groups, sqrt_d, window_len_extra, attention_mask,
                             mask_row_stride, heads_per_mask_row);
@@ -1650,7 +1663,7 @@ int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_ca
                                    const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
                                    int heads_per_mask_row)
 {
-    const mustafar_cache_view none{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const mustafar_cache_view none{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     if (T > 0 && (!k_cache || !v_cache)) return MUSTAFAR_EINVAL;
     return decode_attention(stream, k_cache ? *k_cache : none, v_cache ? *v_cache : none, q, k_window, v_window, k_new, v_new,
                             window_len, window_capacity, scores, ld_scores, out, workspace, Split_K, T, Batch_Size,

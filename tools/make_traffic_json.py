@@ -8,7 +8,7 @@ because the 64-byte scalar/prefetch requests of the metadata (bitmaps, offsets: 
 full size; pricing only the packed stream as wide gives the second figure.
     python tools/make_traffic_json.py gpurun_out/traffic_r1 c3 [metadata_bytes_key metadata_bytes_value]
 """
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
 
 base, cfg = sys.argv[1], sys.argv[2]
 out = {}
@@ -31,6 +31,11 @@ for name, d in res.items():
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "hbm_traffic.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[cfg] = entry
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in ("spmv.hip", "compress.hip"):   # bench.py's kernel_source_tag(): a figure is only reported for the kernels it was measured on
+    h.update(open(os.path.join(ROOT, "mustafar_amd", "csrc", f), "rb").read())
+allj["kernel_source_tag"] = h.hexdigest()[:12]
 allj["_note"] = ("bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB counters; gfx950 FETCH_SIZE halves wide reads, calibrated on a "
                  "256 MiB copy in the same run); upper bound: the 64-byte metadata requests are not halved by the counter")
 json.dump(allj, open(path, "w"), indent=1)
