@@ -201,6 +201,16 @@ int mustafar_set_fma_engine(int engine);
 int mustafar_get_fma_engine(void);
 
 /*
+ * Structure of mustafar_decode_attention{,_view}: 1 (default) = one-pass launch -- every wave runs key phase, softmax step
+ * and value phase on its 64-token blocks and leaves (max, sum, unnormalised output) slabs that a row kernel merges
+ * (flash-decoding over the compressed cache; needs ld_scores % 32 == 0, otherwise the other form runs); 0 = the round-1 form,
+ * key SpMV -> softmax rows -> value SpMV -> sum.  Also MUSTAFAR_ONEPASS=0 in the environment.  Same inputs, same
+ * outputs within fp16 (the one-pass form normalises in fp32 at the end instead of rounding the probabilities to fp16).
+ */
+int mustafar_set_onepass(int enabled);
+int mustafar_get_onepass(void);
+
+/*
  * Live kernel timing inside mustafar_decode_attention (bench.py roofline leg): HIP events that receive the start and
  * stop timestamps of the key and the value SpMV kernels themselves (hipExtLaunchKernel; the same interval rocprofv3
  * reports) for up to `max_records` calls.  mustafar_profile_end() waits for the recorded events, returns the average

@@ -1322,6 +1322,340 @@ __global__ __launch_bounds__(256) void value_finish_kernel(
     if (!par) out[(int64_t)bh * kD + c] = (h16)(s + part[c]);
 }
 
+
+// ------------------------------------------------------------------------------------------------ one-pass decode
+// The whole compressed part of a layer's decode attention in ONE launch (+ a row kernel that merges the partial results):
+// a wave takes a 64-token block of one kv-head group and runs, back to back,
+//   key phase     scores of its 64 tokens for the G heads (key_tokblk, lane = token)
+//   softmax step  x = fp16(fp16(score) / sqrt(d)) (+ mask) as the hook does (llama_mustafar_kernel.py:284-301); running
+//                 maximum of the wave, e = exp(x - max) rounded to fp16, running sum; earlier partial outputs rescaled
+//   value phase   partial output += sum_t e_t * V_t over the same 64 tokens (value_tokblks, lane = channel); the e row
+//                 segment travels to the coefficient loads through the score scratch (128 bytes per head and block,
+//                 written and read back by the SAME wave: a row stride of 64 bytes keeps every segment on scalar-cache
+//                 lines of its own, and the wave waits for its stores before the scalar loads are issued)
+// and the workgroup leaves one slab (max, sum, unnormalised output) per head; the dense window is a few more workgroups
+// of the same launch with slabs of the same form; onepass_finish_kernel merges the slabs of a row (flash-decoding).
+// Against the two-launch form (key SpMV -> softmax rows -> value SpMV -> sum): no softmax launch, one launch boundary
+// and one ramp / tail less, and the value phase of a block starts behind its own key phase instead of behind ALL key
+// blocks.  Numerics: the probabilities are normalised in fp32 at the very end instead of being rounded to fp16 after
+// normalisation (:304); e carries the same 11 bits as the hook's fp16 probabilities.
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+constexpr int kOneWinChunk = 64;   // window tokens per window workgroup of the one-pass launch (one slab each)
+
+struct OneArgs {   // operands of the one-pass launch beyond the two caches (by value: one kernarg block)
+    const h16* q;          // [BH, 128]
+    h16* e_rows;           // [BH, ld] scratch: exp(x - running max) of the compressed part, fp16
+    float* ws_o;           // [slabs, BH, 128] unnormalised partial outputs
+    float* ws_ml;          // [slabs, BH, 2]   (max, sum) of every slab
+    h16* k_win;            // [B', w_cap, 128] dense windows, appended in place
+    h16* v_win;
+    const h16* k_new;      // [B', 128] newest rows (or nullptr: already stored)
+    const h16* v_new;
+    const int* w_extra;    // device step counter added to w_len (graph replay), or nullptr
+    MaskArg mask;
+    int T, groups, BH, tb_per_wg, ld, w_len, w_cap, nchunks, win_rows;
+    float inv_sqrt_d;
+};
+
+// Window workgroup: 64 window tokens of one head batch -> scores, softmax partial, p.V partial -> slab (S + chunk).
+template <int G>
+__device__ __forceinline__ void onepass_window_wg(unsigned char* smem, const OneArgs& a, int task, int S)
+{
+    constexpr int kRedLd = kD + 4;
+    float* xs = reinterpret_cast<float*>(smem);                    // [G][64] scores, then e
+    float* ml = xs + G * 64;                                        // [G][2]
+    float* red = ml + 2 * G;                                        // [16][kRedLd] fold buffer
+    h16* qs = reinterpret_cast<h16*>(red + 16 * kRedLd);            // [G][128]
+    static_assert((G * 64 + 2 * G + 16 * kRedLd) * 4 + G * kD * 2 <= kWaves * kStageBytes, "window scratch must fit in the stage area");
+    const int hb_per_kv = a.groups / G;
+    const int hb = task / a.nchunks, chunk = task % a.nchunks;
+    const int kvh = hb / hb_per_kv, bh0 = kvh * a.groups + (hb % hb_per_kv) * G;
+    const int w_len = window_len(a.w_extra, a.w_len, a.w_cap);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w0 = chunk * kOneWinChunk;
+    float* slab_o = a.ws_o + ((int64_t)(S + chunk) * a.BH + bh0) * kD;
+    float* slab_ml = a.ws_ml + ((int64_t)(S + chunk) * a.BH + bh0) * 2;
+    if (w0 >= w_len) {   // empty chunk (beyond the current window): a slab of weight zero
+        for (int o = tid; o < G * kD; o += kThreads) slab_o[o] = 0.f;
+        if (tid < G) { slab_ml[2 * tid] = -INFINITY; slab_ml[2 * tid + 1] = 0.f; }
+        return;
+    }
+    const bool first_hb = hb % hb_per_kv == 0;
+    // ---- scores: 4 threads per token (32 channels each), q rows of the G heads in LDS (llama_mustafar_kernel.py:270, :278)
+    if (tid < G * 16) reinterpret_cast<uint4*>(qs)[tid] = reinterpret_cast<const uint4*>(a.q + (int64_t)bh0 * kD)[tid];
+    const int row = tid >> 2, part = tid & 3;
+    const int w = w0 + row;
+    const bool valid = w < w_len;
+    const int wr = valid ? w : w_len - 1;
+    const h16* kfresh = a.k_new ? a.k_new + (int64_t)kvh * kD : nullptr;
+    h16* kwin = a.k_win + (int64_t)kvh * a.w_cap * kD;
+    const h16* kr = ((kfresh && wr == w_len - 1) ? kfresh : kwin + (int64_t)wr * kD) + part * 32;
+    Vec8 kv[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) kv[c].u = reinterpret_cast<const uint4*>(kr)[c];
+    if (kfresh && valid && w == w_len - 1 && first_hb) {   // store the new key row (:270)
+#pragma unroll
+        for (int c = 0; c < 4; c++) reinterpret_cast<uint4*>(kwin + (int64_t)w * kD + part * 32)[c] = kv[c].u;
+    }
+    __syncthreads();
+    const h16* mrow = a.mask.ptr ? a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride + a.T : nullptr;
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            Vec8 qv;
+            qv.u = reinterpret_cast<const uint4*>(qs + h * kD + part * 32)[c];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc = __builtin_fmaf((float)kv[c].h[j], (float)qv.h[j], acc);
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (part == 0) {
+            float x = -INFINITY;
+            if (valid) {
+                x = scaled((h16)acc, a.inv_sqrt_d);          // fp16 score (:278), / sqrt(d) in fp16 (:284)
+                if (mrow) x = masked(x, mrow[w]);
+            }
+            xs[h * 64 + row] = x;
+        }
+    }
+    __syncthreads();
+    if (wave < G) {   // softmax partial of head `wave` over the chunk's tokens (lane = token)
+        const float x = xs[wave * 64 + lane];
+        const float m = wave_max(x);
+        const float e = (float)(h16)__expf(x - m);           // (exp(-inf - m) = 0 for the lanes beyond the window)
+        xs[wave * 64 + lane] = e;
+        const float l = wave_sum(e);
+        if (lane == 0) { ml[2 * wave] = m; ml[2 * wave + 1] = l; }
+    }
+    __syncthreads();
+    // ---- p.V over the chunk's tokens (:309, :316): 16 lanes x 16 bytes per row, 16 rows per sweep
+    const int sub = tid & 15, grp = tid >> 4;
+    const h16* vfresh = a.v_new ? a.v_new + (int64_t)kvh * kD : nullptr;
+    h16* vwin = a.v_win + (int64_t)kvh * a.w_cap * kD;
+    const int w1 = min(w0 + kOneWinChunk, w_len);
+    float acc[G][8];
+#pragma unroll
+    for (int h = 0; h < G; h++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[h][j] = 0.f;
+    Vec8 vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int ww = w0 + grp + u * 16;
+        const int wr2 = ww < w1 ? ww : w0;
+        const h16* vr = (vfresh && wr2 == w_len - 1) ? vfresh : vwin + (int64_t)wr2 * kD;
+        vv[u].u = reinterpret_cast<const uint4*>(vr)[sub];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int ww = w0 + grp + u * 16;
+        if (ww < w1) {
+            if (vfresh && ww == w_len - 1 && first_hb)   // store the new value row (:309)
+                reinterpret_cast<uint4*>(vwin + (int64_t)ww * kD)[sub] = vv[u].u;
+#pragma unroll
+            for (int h = 0; h < G; h++) {
+                const float pw = xs[h * 64 + (ww - w0)];
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[h][j] = __builtin_fmaf(pw, (float)vv[u].h[j], acc[h][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[grp * kRedLd + sub * 8 + j] = acc[h][j];
+        __syncthreads();
+        if (tid < kD) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; g++) sum += red[g * kRedLd + tid];
+            slab_o[h * kD + tid] = sum;
+        }
+    }
+    if (tid < 2 * G) slab_ml[tid] = ml[tid];
+}
+
+// grid: x = token chunks (tb_per_wg blocks each; wave w takes blocks tb0 + w, tb0 + w + 4, ...), y = kv-heads * (groups / G)
+// (+ win_rows leading rows of window workgroups).  4 waves.
+template <int G, bool MF>
+__global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
+    const uint64_t* __restrict__ k_bmp, const unsigned char* __restrict__ k_nz, const uint32_t* __restrict__ k_idx,
+    const uint32_t* __restrict__ k_nz_off, const uint64_t* __restrict__ v_bmp, const unsigned char* __restrict__ v_nz,
+    const uint32_t* __restrict__ v_idx, const uint32_t* __restrict__ v_nz_off, OneArgs a, int64_t k_bmp_stride,
+    int64_t k_idx_stride, uint32_t k_nz_stride, int64_t v_bmp_stride, int64_t v_idx_stride, uint32_t v_nz_stride)
+{
+    constexpr int kTabBytes = (MF && G == 4) ? 4 * kKeyTabStride + kWaves * 4 * kValTabStride : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
+    static_assert(kWaves * kStageBytes >= (kWaves * 2 * 4 * 64 + 2 * kWaves * 4) * 4, "combine buffers must fit in the stage area");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.x;
+    if ((int)blockIdx.y < a.win_rows) {   // dense window
+        const int task = blockIdx.y * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - a.win_rows) * a.nchunks) onepass_window_wg<G>(smem, a, task, S);
+        return;
+    }
+    const int by = blockIdx.y - a.win_rows;
+    const int hb_per_kv = a.groups / G;
+    const int kvh = by / hb_per_kv;
+    const int bh0 = kvh * a.groups + (by % hb_per_kv) * G;
+    const int ntb = a.T >> 6;
+    const int tb0 = blockIdx.x * a.tb_per_wg;
+    const int tb_end = min(ntb, tb0 + a.tb_per_wg);
+    const int64_t tiles = (int64_t)ntb * kTilesPerTb;
+    const uint64_t* kb = k_bmp + (int64_t)kvh * (k_bmp_stride ? k_bmp_stride : tiles);
+    const uint32_t* ki = k_idx + (int64_t)kvh * (k_idx_stride ? k_idx_stride : tiles + 1);
+    const unsigned char* kn = k_nz + 16ull * (k_nz_stride ? (uint64_t)kvh * k_nz_stride : (uint64_t)k_nz_off[kvh]);
+    const uint64_t* vb = v_bmp + (int64_t)kvh * (v_bmp_stride ? v_bmp_stride : tiles);
+    const uint32_t* vi = v_idx + (int64_t)kvh * (v_idx_stride ? v_idx_stride : tiles + 1);
+    const unsigned char* vn = v_nz + 16ull * (v_nz_stride ? (uint64_t)kvh * v_nz_stride : (uint64_t)v_nz_off[kvh]);
+    const h16x2* qw = reinterpret_cast<const h16x2*>(a.q + (int64_t)bh0 * kD);
+    h16* erow = a.e_rows + (int64_t)bh0 * a.ld;
+    const h16x2* pw = reinterpret_cast<const h16x2*>(erow);
+    const h16* mrow = a.mask.ptr ? a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride : nullptr;
+
+    uint32_t ctab_lane = 0;
+    unsigned char* ptab = nullptr;
+    if constexpr (MF && G == 4) {   // key-side coefficient table: the q rows of the 4 heads (as key_spmv_kernel)
+        unsigned char* tab = smem + kWaves * kStageBytes;
+        if (threadIdx.x < 64)
+            *reinterpret_cast<uint4*>(tab + (threadIdx.x >> 4) * kKeyTabStride + (threadIdx.x & 15) * 16) =
+                *reinterpret_cast<const uint4*>(a.q + (int64_t)(bh0 + (threadIdx.x >> 4)) * kD + (threadIdx.x & 15) * 8);
+        __syncthreads();
+        ctab_lane = (uint32_t)reinterpret_cast<uintptr_t>(tab) + (lane & 3) * kKeyTabStride;
+        ptab = tab + 4 * kKeyTabStride + wave * (4 * kValTabStride);
+    }
+
+    float m_run[G], l_lane[G], acc0[G], acc1[G];
+#pragma unroll
+    for (int h = 0; h < G; h++) { m_run[h] = -INFINITY; l_lane[h] = 0.f; acc0[h] = 0.f; acc1[h] = 0.f; }
+    for (int tb = tb0 + wave; tb < tb_end; tb += kWaves) {
+        float s[G];
+#pragma unroll
+        for (int h = 0; h < G; h++) s[h] = 0.f;
+        key_tokblk<G, MF, 0, 4>(smem, wave * kStageBytes, kb + (int64_t)tb * kTilesPerTb, ki + (int64_t)tb * kTilesPerTb, kn, qw, kD / 2,
+                                lane, s, ctab_lane);
+        h16 mk = (h16)0.f;
+        if (mrow) mk = mrow[tb * 64 + lane];
+#pragma unroll
+        for (int h = 0; h < G; h++) {
+            float x = scaled((h16)s[h], a.inv_sqrt_d);        // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
+            if (mrow) x = masked(x, mk);
+            const float m_new = fmaxf(m_run[h], wave_max(x));
+            const float alpha = __expf(m_run[h] - m_new);     // 0 for the wave's first block (m_run = -inf)
+            const h16 e = (h16)__expf(x - m_new);
+            erow[(int64_t)h * a.ld + tb * 64 + lane] = e;
+            l_lane[h] = l_lane[h] * alpha + (float)e;
+            acc0[h] *= alpha;
+            acc1[h] *= alpha;
+            m_run[h] = m_new;
+        }
+        // the value phase reads the e segments back as coefficients: through scalar loads (VALU engine) or one vector
+        // load into the per-wave table (matrix-pipe engine) -- after the stores have reached L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (MF && G == 4) {
+            float b0[G], b1[G];
+            value_tokblks<G, MF, 0, 4, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, b0, b1, ptab);
+#pragma unroll
+            for (int h = 0; h < G; h++) { acc0[h] += b0[h]; acc1[h] += b1[h]; }
+        } else {
+            value_tokblks<G, MF, 0, 4, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
+        }
+    }
+    // ---- merge the 4 waves: common maximum, rescaled sums and outputs -> one slab per head
+    float* red = reinterpret_cast<float*>(smem);                 // [kWaves][2G][64]
+    float* s_m = red + kWaves * 2 * G * 64;                      // [kWaves][G]
+    float* s_l = s_m + kWaves * G;                               // [kWaves][G]
+    __syncthreads();   // every wave is done with its stage window
+    if (lane < G) {
+        float mine = m_run[0];
+#pragma unroll
+        for (int h = 1; h < G; h++) mine = (lane == h) ? m_run[h] : mine;
+        s_m[wave * G + lane] = mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        float M = s_m[h];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) M = fmaxf(M, s_m[w * G + h]);
+        const float scale = (m_run[h] == -INFINITY) ? 0.f : __expf(m_run[h] - M);   // a wave without blocks weighs nothing
+        const float l = wave_sum(l_lane[h]) * scale;
+        if (lane == 0) s_l[wave * G + h] = l;
+        red[(wave * 2 * G + h) * 64 + lane]     = acc0[h] * scale;
+        red[(wave * 2 * G + G + h) * 64 + lane] = acc1[h] * scale;
+    }
+    __syncthreads();
+    float* slab_o = a.ws_o + ((int64_t)blockIdx.x * a.BH + bh0) * kD;
+    for (int o = threadIdx.x; o < 2 * G * 64; o += kThreads) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) sum += red[w * 2 * G * 64 + o];
+        const int hh = o >> 6, l = o & 63;   // hh = half * G + h
+        slab_o[(hh % G) * kD + (hh / G) * 64 + l] = sum;
+    }
+    if (threadIdx.x < G) {
+        const int h = threadIdx.x;
+        float M = s_m[h], L = s_l[h];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) { M = fmaxf(M, s_m[w * G + h]); L += s_l[w * G + h]; }
+        float* slab_ml = a.ws_ml + ((int64_t)blockIdx.x * a.BH + bh0 + h) * 2;
+        slab_ml[0] = M;
+        slab_ml[1] = L;
+    }
+}
+
+// out[bh, c] = fp16( sum_s w_s * o_s[c] / sum_s w_s * l_s ),  w_s = exp(m_s - max_s m_s)   (the softmax of :304 and the
+// sums of :315-317, merged over the slabs of the row).  One workgroup per row, 256 threads: thread = (channel, parity).
+constexpr int kMaxSlabs = 512;
+__global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml,
+                                                             int S, h16* __restrict__ out, int BH)
+{
+    __shared__ float wgt[kMaxSlabs];
+    __shared__ float sh[4];
+    __shared__ float part[kD];
+    const int bh = blockIdx.x, tid = threadIdx.x;
+    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;   // slabs tid and tid + 256
+    if (tid < S) { m0 = ws_ml[((int64_t)tid * BH + bh) * 2]; l0 = ws_ml[((int64_t)tid * BH + bh) * 2 + 1]; }
+    if (tid + 256 < S) { m1 = ws_ml[((int64_t)(tid + 256) * BH + bh) * 2]; l1 = ws_ml[((int64_t)(tid + 256) * BH + bh) * 2 + 1]; }
+    const float M = block_reduce<4>(fmaxf(m0, m1), true, sh);
+    const float w0 = (l0 > 0.f) ? __expf(m0 - M) : 0.f, w1 = (l1 > 0.f) ? __expf(m1 - M) : 0.f;
+    if (tid < S) wgt[tid] = w0;
+    if (tid + 256 < S) wgt[tid + 256] = w1;
+    const float denom = block_reduce<4>(w0 * l0 + w1 * l1, false, sh);   // (its barriers also publish wgt[])
+    const int c = tid & (kD - 1), par = tid >> 7;
+    const int64_t total = (int64_t)BH * kD;
+    const float* src = ws_o + (int64_t)bh * kD + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = par;
+    for (; k + 6 < S; k += 8) {
+        s0 += wgt[k] * src[(int64_t)k * total];
+        s1 += wgt[k + 2] * src[(int64_t)(k + 2) * total];
+        s2 += wgt[k + 4] * src[(int64_t)(k + 4) * total];
+        s3 += wgt[k + 6] * src[(int64_t)(k + 6) * total];
+    }
+    for (; k < S; k += 2) s0 += wgt[k] * src[(int64_t)k * total];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (par) part[c] = s;
+    __syncthreads();
+    if (!par) out[(int64_t)bh * kD + c] = (h16)((s + part[c]) / denom);
+}
+
 inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : 1; }
 
 // FMA engine of the G = 4 kernels: 0 = VALU (v_fma_mix_f32; default, MFMA left off as the north_star asks),
@@ -1365,6 +1699,17 @@ inline bool window_rows_last(int side)
     }
     return (g_window_last >> side) & 1;
 }
+// Structure of the fused decode entry point: 1 = one-pass launch (decode_onepass_kernel + onepass_finish_kernel; default),
+// 0 = key SpMV -> softmax rows -> value SpMV -> sum (MUSTAFAR_ONEPASS=0 / mustafar_set_onepass(0)).
+int g_onepass = -1;
+inline int onepass_enabled()
+{
+    if (g_onepass < 0) {
+        const char* e = getenv("MUSTAFAR_ONEPASS");
+        g_onepass = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_onepass;
+}
 int g_engine = -1;
 inline int fma_engine()
 {
@@ -1381,7 +1726,8 @@ inline int fma_engine()
 struct Profile {
     bool on = false;
     int cap = 0, n = 0;
-    hipEvent_t* ev = nullptr;   // 4 per record: key begin/end, value begin/end
+    hipEvent_t* ev = nullptr;   // 4 per record: key begin/end, value begin/end (one-pass launch: the first pair only)
+    int onepass = 0;            // records taken on the one-pass launch
 } g_prof;
 
 
@@ -1557,8 +1903,9 @@ int Value_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const
 
 int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value_groups, int Split_K)
 {
-    (void)T; (void)num_key_value_groups;   // token-chunk slabs + the window workgroups' partial slabs
-    return (int64_t)((Split_K < 1 ? 1 : Split_K) + kMaxWindow / kValueWinChunk) * Batch_Size * kD * (int64_t)sizeof(float);
+    (void)T; (void)num_key_value_groups;   // token-chunk slabs + the window workgroups' slabs (one-pass form: 64-token window
+    // chunks and a (max, sum) pair per slab and row)
+    return (int64_t)((Split_K < 1 ? 1 : Split_K) + kMaxWindow / kOneWinChunk) * Batch_Size * (kD + 2) * (int64_t)sizeof(float);
 }
 
 }  // extern "C"
@@ -1594,8 +1941,43 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     auto vwin = static_cast<h16*>(v_window);
     auto knew = static_cast<const h16*>(k_new);
     auto vnew = static_cast<const h16*>(v_new);
-    // With a compressed part the dense-window work rides in the two SpMV launches (window workgroups); without one
-    // (T == 0) the two row kernels do it themselves.
+    const float inv_sqrt_d0 = (float)(1.0 / (double)sqrt_d);
+    if (T > 0 && onepass_enabled() && (ld_scores & 31) == 0) {
+        // ---- one-pass form: every wave runs key phase -> softmax step -> value phase on its token blocks; slabs merged per row
+        const int ntb = T / 64;
+        int tb_per_wg = (ntb + Split_K - 1) / Split_K;
+        tb_per_wg = (tb_per_wg + kWaves - 1) / kWaves * kWaves;          // whole rounds of the 4 waves
+        const int S1 = (ntb + tb_per_wg - 1) / tb_per_wg;
+        const int nchunks = (window_capacity + kOneWinChunk - 1) / kOneWinChunk;
+        if (S1 + nchunks <= kMaxSlabs) {
+            float* ws_o = static_cast<float*>(workspace);
+            float* ws_ml = ws_o + (int64_t)(S1 + nchunks) * Batch_Size * kD;
+            const int win_rows = (gy * nchunks + S1 - 1) / S1;
+            const OneArgs a{qh, sc, ws_o, ws_ml, kwin, vwin, knew, vnew, window_len_extra, mask, T, groups, Batch_Size, tb_per_wg, ld_scores,
+                            window_len, window_capacity, nchunks, win_rows, inv_sqrt_d0};
+            const dim3 grid(S1, gy + win_rows);
+            hipEvent_t e0 = prof ? g_prof.ev[4 * g_prof.n] : nullptr, e1 = prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr;
+            auto kz = static_cast<const unsigned char*>(kc.nz), vz = static_cast<const unsigned char*>(vc.nz);
+#define MUSTAFAR_L1(GG, MFF)                                                                                                     \
+    hipExtLaunchKernelGGL((decode_onepass_kernel<GG, MFF>), grid, dim3(kThreads), 0, st, e0, e1, 0, kc.bmp, kz, kc.idx, kc.nz_offset,  \
+                          vc.bmp, vz, vc.idx, vc.nz_offset, a, kc.bmp_head_stride, kc.idx_head_stride, (uint32_t)kc.nz_head_stride,    \
+                          vc.bmp_head_stride, vc.idx_head_stride, (uint32_t)vc.nz_head_stride)
+            switch (G) {
+                case 4:
+                    if (fma_engine()) MUSTAFAR_L1(4, true);
+                    else              MUSTAFAR_L1(4, false);
+                    break;
+                case 2: MUSTAFAR_L1(2, false); break;
+                default: MUSTAFAR_L1(1, false); break;
+            }
+#undef MUSTAFAR_L1
+            if (prof) { g_prof.onepass++; g_prof.n++; }
+            onepass_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, S1 + nchunks, static_cast<h16*>(out), Batch_Size);
+            return (int)hipGetLastError();
+        }
+    }
+    // ---- two-launch form.  With a compressed part the dense-window work rides in the two SpMV launches (window workgroups);
+    // without one (T == 0) the two row kernels do it themselves.
     const bool long_rows = T > kMaxRowVecs * kGlueThreads * 8;   // beyond the register form of the softmax kernel
     const bool ride_k = T > 0 && ((window_ride_mask() & 1) || long_rows), ride_v = T > 0 && (window_ride_mask() & 2);
     if (T > 0) {
@@ -1693,13 +2075,16 @@ int mustafar_profile_end(double* key_us_avg, double* value_us_avg, int* records)
     if (!g_prof.ev) return MUSTAFAR_EINVAL;
     g_prof.on = false;
     double k = 0, v = 0;
+    const bool one = g_prof.onepass == g_prof.n && g_prof.n > 0;   // every record is a one-pass launch: no value launch exists
     for (int i = 0; i < g_prof.n; i++) {
         float ms = 0;
-        (void)hipEventSynchronize(g_prof.ev[4 * i + 3]);
+        (void)hipEventSynchronize(g_prof.ev[4 * i + (one ? 1 : 3)]);
         (void)hipEventElapsedTime(&ms, g_prof.ev[4 * i], g_prof.ev[4 * i + 1]);
         k += ms * 1e3;
-        (void)hipEventElapsedTime(&ms, g_prof.ev[4 * i + 2], g_prof.ev[4 * i + 3]);
-        v += ms * 1e3;
+        if (!one) {
+            (void)hipEventElapsedTime(&ms, g_prof.ev[4 * i + 2], g_prof.ev[4 * i + 3]);
+            v += ms * 1e3;
+        }
     }
     if (records) *records = g_prof.n;
     if (key_us_avg) *key_us_avg = g_prof.n ? k / g_prof.n : 0;
@@ -1727,6 +2112,15 @@ int mustafar_set_fma_engine(int engine)
 }
 
 int mustafar_get_fma_engine(void) { return fma_engine(); }
+
+int mustafar_set_onepass(int enabled)
+{
+    if (enabled != 0 && enabled != 1) return MUSTAFAR_EINVAL;
+    g_onepass = enabled;
+    return 0;
+}
+
+int mustafar_get_onepass(void) { return onepass_enabled(); }
 
 #ifdef MUSTAFAR_WAVE_TRACE
 // Tool-only (tools/wave_trace.py): records go to `buf` (4 x u64 each, `cap` slots; zero it first).

@@ -267,7 +267,7 @@ class MustafarAttention:
         dev = query_states.device
         L = _lib.load()
         split = L.mustafar_value_pick_split_k(128, 1, C, BH, groups) if C else 1
-        ld = (C + max(k_w.cap, v_w.cap) + 7) // 8 * 8
+        ld = (C + max(k_w.cap, v_w.cap) + 31) // 32 * 32   # rows on 64-byte lines of their own (one-pass form: mustafar_hip.h)
         scores, ws = self._scratch(dev, BH, ld, L.mustafar_decode_workspace_bytes(C, BH, groups, split))
         out = torch.empty((bsz, self.num_heads, 1, D), dtype=torch.float16, device=dev)
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
