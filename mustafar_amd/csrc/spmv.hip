@@ -1490,9 +1490,13 @@ __device__ __forceinline__ void onepass_window_wg(unsigned char* smem, const One
     if (tid < 2 * G) slab_ml[tid] = ml[tid];
 }
 
-// grid: x = token chunks (tb_per_wg blocks each; wave w takes blocks tb0 + w, tb0 + w + 4, ...), y = kv-heads * (groups / G)
-// (+ win_rows leading rows of window workgroups).  4 waves.
-template <int G, bool MF>
+// grid: x = token chunks (tb_per_wg blocks each), y = kv-heads * (groups / G) (+ win_rows leading rows of window
+// workgroups).  4 waves; PAIR = false: wave w takes blocks tb0 + w, tb0 + w + 4, ... whole; PAIR = true: two waves share a
+// block -- 64 channels each in the key phase (partial scores folded through LDS), one 64-channel half of the output each in
+// the value phase -- and the workgroup walks two blocks at a time with two barriers per step.  The finer grain is what the
+// VALU engine wants (its two-launch forms of the same grain: key 24.6 vs 25.8 us, value 29.5 vs 34.9 us at c3); the
+// matrix-pipe engine is faster with whole blocks.
+template <int G, bool MF, bool PAIR>
 __global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
     const uint64_t* __restrict__ k_bmp, const unsigned char* __restrict__ k_nz, const uint32_t* __restrict__ k_idx,
     const uint32_t* __restrict__ k_nz_off, const uint64_t* __restrict__ v_bmp, const unsigned char* __restrict__ v_nz,
@@ -1541,15 +1545,13 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
         ptab = tab + 4 * kKeyTabStride + wave * (4 * kValTabStride);
     }
 
+    static_assert(!(MF && PAIR), "the matrix-pipe engine runs whole blocks per wave");
     float m_run[G], l_lane[G], acc0[G], acc1[G];
 #pragma unroll
     for (int h = 0; h < G; h++) { m_run[h] = -INFINITY; l_lane[h] = 0.f; acc0[h] = 0.f; acc1[h] = 0.f; }
-    for (int tb = tb0 + wave; tb < tb_end; tb += kWaves) {
-        float s[G];
-#pragma unroll
-        for (int h = 0; h < G; h++) s[h] = 0.f;
-        key_tokblk<G, MF, 0, 4>(smem, wave * kStageBytes, kb + (int64_t)tb * kTilesPerTb, ki + (int64_t)tb * kTilesPerTb, kn, qw, kD / 2,
-                                lane, s, ctab_lane);
+    // softmax step of one block on the lanes' scores s[] (lane = token): running maximum, e -> the score scratch, running
+    // sum; returns the factors the earlier partial outputs are rescaled by
+    auto softmax_step = [&](int tb, float (&s)[G], float (&alpha)[G]) {
         h16 mk = (h16)0.f;
         if (mrow) mk = mrow[tb * 64 + lane];
 #pragma unroll
@@ -1557,44 +1559,106 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
             float x = scaled((h16)s[h], a.inv_sqrt_d);        // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
             if (mrow) x = masked(x, mk);
             const float m_new = fmaxf(m_run[h], wave_max(x));
-            const float alpha = __expf(m_run[h] - m_new);     // 0 for the wave's first block (m_run = -inf)
+            alpha[h] = __expf(m_run[h] - m_new);              // 0 for the first block (m_run = -inf)
             const h16 e = (h16)__expf(x - m_new);
             erow[(int64_t)h * a.ld + tb * 64 + lane] = e;
-            l_lane[h] = l_lane[h] * alpha + (float)e;
-            acc0[h] *= alpha;
-            acc1[h] *= alpha;
+            l_lane[h] = l_lane[h] * alpha[h] + (float)e;
             m_run[h] = m_new;
         }
-        // the value phase reads the e segments back as coefficients: through scalar loads (VALU engine) or one vector
-        // load into the per-wave table (matrix-pipe engine) -- after the stores have reached L2
+        // the value phase reads the e segments back as coefficients (scalar loads / one vector load into the per-wave
+        // table): after the stores have reached L2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (MF && G == 4) {
-            float b0[G], b1[G];
-            value_tokblks<G, MF, 0, 4, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, b0, b1, ptab);
+    };
+    if constexpr (!PAIR) {
+        for (int tb = tb0 + wave; tb < tb_end; tb += kWaves) {
+            float s[G], alpha[G];
 #pragma unroll
-            for (int h = 0; h < G; h++) { acc0[h] += b0[h]; acc1[h] += b1[h]; }
-        } else {
-            value_tokblks<G, MF, 0, 4, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
+            for (int h = 0; h < G; h++) s[h] = 0.f;
+            key_tokblk<G, MF, 0, 4>(smem, wave * kStageBytes, kb + (int64_t)tb * kTilesPerTb, ki + (int64_t)tb * kTilesPerTb, kn, qw, kD / 2,
+                                    lane, s, ctab_lane);
+            softmax_step(tb, s, alpha);
+#pragma unroll
+            for (int h = 0; h < G; h++) { acc0[h] *= alpha[h]; acc1[h] *= alpha[h]; }
+            if constexpr (MF && G == 4) {
+                float b0[G], b1[G];
+                value_tokblks<G, MF, 0, 4, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, b0, b1, ptab);
+#pragma unroll
+                for (int h = 0; h < G; h++) { acc0[h] += b0[h]; acc1[h] += b1[h]; }
+            } else {
+                value_tokblks<G, MF, 0, 4, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
+            }
+        }
+    } else {
+        const int pair = wave >> 1, odd = wave & 1;
+        // exchange area of the pair: the ODD wave's stage window (dead between the phases): G x 64 partial scores, then G factors
+        float* xch = reinterpret_cast<float*>(smem + (2 * pair + 1) * kStageBytes);
+        for (int t = tb0; t < tb_end; t += kWaves / 2) {   // workgroup-uniform: the barriers below are reached by every wave
+            const int tb = t + pair;
+            const bool active = tb < tb_end;
+            float s[G], alpha[G];
+#pragma unroll
+            for (int h = 0; h < G; h++) { s[h] = 0.f; alpha[h] = 1.f; }
+            if (active) {
+                const uint64_t* kbt = kb + (int64_t)tb * kTilesPerTb;
+                const uint32_t* kit = ki + (int64_t)tb * kTilesPerTb;
+                if (odd) key_tokblk<G, MF, 2, 2>(smem, wave * kStageBytes, kbt, kit, kn, qw, kD / 2, lane, s, ctab_lane);
+                else     key_tokblk<G, MF, 0, 2>(smem, wave * kStageBytes, kbt, kit, kn, qw, kD / 2, lane, s, ctab_lane);
+                if (odd) {
+#pragma unroll
+                    for (int h = 0; h < G; h++) xch[h * 64 + lane] = s[h];
+                }
+            }
+            __syncthreads();
+            if (active && !odd) {
+#pragma unroll
+                for (int h = 0; h < G; h++) s[h] += xch[h * 64 + lane];
+                softmax_step(tb, s, alpha);
+                if (lane < G) {
+                    float mine = alpha[0];
+#pragma unroll
+                    for (int h = 1; h < G; h++) mine = (lane == h) ? alpha[h] : mine;
+                    xch[G * 64 + lane] = mine;
+                }
+            }
+            __syncthreads();
+            if (active) {
+                if (odd) {
+#pragma unroll
+                    for (int h = 0; h < G; h++) alpha[h] = xch[G * 64 + h];
+                }
+#pragma unroll
+                for (int h = 0; h < G; h++) { acc0[h] *= alpha[h]; acc1[h] *= alpha[h]; }
+                // (the odd wave's LDS reads above are issued before its value phase rewrites the window: one wave, in order)
+                if (odd) value_tokblks<G, MF, 2, 2, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
+                else     value_tokblks<G, MF, 0, 2, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
+            }
+        }
+        if (odd) {   // maximum and sum live in the even wave; the odd wave contributes its output half only
+#pragma unroll
+            for (int h = 0; h < G; h++) l_lane[h] = 0.f;
         }
     }
-    // ---- merge the 4 waves: common maximum, rescaled sums and outputs -> one slab per head
+    // ---- merge the waves: common maximum, rescaled sums and outputs -> one slab per head.  (PAIR: an odd wave carries
+    // the second channel half of its pair's blocks and must be scaled by the PAIR's maximum: it borrows the even wave's.)
     float* red = reinterpret_cast<float*>(smem);                 // [kWaves][2G][64]
     float* s_m = red + kWaves * 2 * G * 64;                      // [kWaves][G]
     float* s_l = s_m + kWaves * G;                               // [kWaves][G]
     __syncthreads();   // every wave is done with its stage window
-    if (lane < G) {
+    if (lane < G && !(PAIR && (wave & 1))) {
         float mine = m_run[0];
 #pragma unroll
         for (int h = 1; h < G; h++) mine = (lane == h) ? m_run[h] : mine;
         s_m[wave * G + lane] = mine;
+        if (PAIR) s_m[(wave + 1) * G + lane] = mine;
     }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < G; h++) {
+        const float mw = s_m[wave * G + h];                      // (= m_run[h], or the partner's for an odd wave of a pair)
         float M = s_m[h];
 #pragma unroll
         for (int w = 1; w < kWaves; w++) M = fmaxf(M, s_m[w * G + h]);
-        const float scale = (m_run[h] == -INFINITY) ? 0.f : __expf(m_run[h] - M);   // a wave without blocks weighs nothing
+        const float scale = (mw == -INFINITY) ? 0.f : __expf(mw - M);   // a wave without blocks weighs nothing
         const float l = wave_sum(l_lane[h]) * scale;
         if (lane == 0) s_l[wave * G + h] = l;
         red[(wave * 2 * G + h) * 64 + lane]     = acc0[h] * scale;
@@ -1945,8 +2009,10 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     if (T > 0 && onepass_enabled() && (ld_scores & 31) == 0) {
         // ---- one-pass form: every wave runs key phase -> softmax step -> value phase on its token blocks; slabs merged per row
         const int ntb = T / 64;
+        const bool pair = !fma_engine() || G != 4;                      // two waves per block unless the matrix-pipe engine runs
+        const int round = pair ? kWaves / 2 : kWaves;                     // token blocks a workgroup has in flight
         int tb_per_wg = (ntb + Split_K - 1) / Split_K;
-        tb_per_wg = (tb_per_wg + kWaves - 1) / kWaves * kWaves;          // whole rounds of the 4 waves
+        tb_per_wg = (tb_per_wg + round - 1) / round * round;             // whole rounds of the 4 waves
         const int S1 = (ntb + tb_per_wg - 1) / tb_per_wg;
         const int nchunks = (window_capacity + kOneWinChunk - 1) / kOneWinChunk;
         if (S1 + nchunks <= kMaxSlabs) {
@@ -1959,7 +2025,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             hipEvent_t e0 = prof ? g_prof.ev[4 * g_prof.n] : nullptr, e1 = prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr;
             auto kz = static_cast<const unsigned char*>(kc.nz), vz = static_cast<const unsigned char*>(vc.nz);
 #define MUSTAFAR_L1(GG, MFF)                                                                                                     \
-    hipExtLaunchKernelGGL((decode_onepass_kernel<GG, MFF>), grid, dim3(kThreads), 0, st, e0, e1, 0, kc.bmp, kz, kc.idx, kc.nz_offset,  \
+    hipExtLaunchKernelGGL((decode_onepass_kernel<GG, MFF, !MFF>), grid, dim3(kThreads), 0, st, e0, e1, 0, kc.bmp, kz, kc.idx, kc.nz_offset,  \
                           vc.bmp, vz, vc.idx, vc.nz_offset, a, kc.bmp_head_stride, kc.idx_head_stride, (uint32_t)kc.nz_head_stride,    \
                           vc.bmp_head_stride, vc.idx_head_stride, (uint32_t)vc.nz_head_stride)
             switch (G) {
