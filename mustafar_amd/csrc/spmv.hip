@@ -828,7 +828,7 @@ __global__ MUSTAFAR_KEY_BOUNDS void key_spmv_kernel(
 // ------------------------------------------------------------------------------------------------ value
 // Accumulate token blocks tb_first, tb_first+4, ... < tb_end of one kv-head: lane = channel,
 // acc0 = channels 0..63, acc1 = channels 64..127, coefficient row `pw` (head stride `chead` pairs).
-template <int G, bool MF, int CB, int CN, int STRIDE>   // chunks [CB, CB + CN) of every STRIDE-th token block
+template <int G, bool MF, int CB, int CN, int STRIDE, bool PTAB_READY = false>   // chunks [CB, CB + CN) of every STRIDE-th token block
 __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_off,
                                               const uint64_t* __restrict__ bmp_h, const uint32_t* __restrict__ idx_h,
                                               const unsigned char* __restrict__ nz_h, const h16x2* __restrict__ pw,
@@ -841,6 +841,10 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
     // MFMA engine: per-wave coefficient table [4 heads][64 tokens] of the current token block (4 x kValTabStride B), filled by
     // lanes 0..31 (16 B each) one token block ahead; lane l reads the row of head l % 4.
     f32x4 accv0 = {0.f, 0.f, 0.f, 0.f}, accv1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MF && G == 4) {   // continue from the caller's sums (zero in the two-launch kernel, the running partial output in the one-pass launch)
+#pragma unroll
+        for (int h = 0; h < 4; h++) { accv0[h] = acc0[h]; accv1[h] = acc1[h]; }
+    }
     uint32_t ctab_lane = 0;
     uint4 ptv = {0u, 0u, 0u, 0u};
     auto ptab_load = [&](int tb) -> uint4 {
@@ -849,8 +853,10 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
     };
     if constexpr (MF && G == 4) {
         ctab_lane = (uint32_t)reinterpret_cast<uintptr_t>(ptab) + (lane & 3) * kValTabStride;
-        ptv = ptab_load(tb_first);
-        if (lane < 32) *reinterpret_cast<uint4*>(ptab + (lane >> 3) * kValTabStride + (lane & 7) * 16) = ptv;
+        if constexpr (!PTAB_READY) {   // (PTAB_READY: the caller filled the table of its single block -- the one-pass launch)
+            ptv = ptab_load(tb_first);
+            if (lane < 32) *reinterpret_cast<uint4*>(ptab + (lane >> 3) * kValTabStride + (lane & 7) * 16) = ptv;
+        }
     }
     uint32_t pf = prefetch_meta<G>(bmp_h + (int64_t)tb_first * kTilesPerTb, idx_h + (int64_t)tb_first * kTilesPerTb,
                                    pw + (uint32_t)tb_first * 32u, chead, lane);
@@ -869,7 +875,7 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
         pf = prefetch_meta<G>(bmp_h + (int64_t)tbn * kTilesPerTb, idx_h + (int64_t)tbn * kTilesPerTb,
                               pw + (uint32_t)tbn * 32u, chead, lane);
         const uint32_t bnd_next = bnd_load(more ? idx_t + STRIDE * kTilesPerTb : idx_t, lane);
-        if constexpr (MF && G == 4) ptv = ptab_load(tbn);
+        if constexpr (MF && G == 4 && !PTAB_READY) ptv = ptab_load(tbn);
 #pragma unroll
         for (int c = CB; c < CB + CN; c++) {
             uint32_t n0 = 0, nlen = 0;
@@ -1447,11 +1453,6 @@ __device__ __forceinline__ void onepass_window_wg(unsigned char* smem, const One
     const h16* vfresh = a.v_new ? a.v_new + (int64_t)kvh * kD : nullptr;
     h16* vwin = a.v_win + (int64_t)kvh * a.w_cap * kD;
     const int w1 = min(w0 + kOneWinChunk, w_len);
-    float acc[G][8];
-#pragma unroll
-    for (int h = 0; h < G; h++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[h][j] = 0.f;
     Vec8 vv[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -1463,22 +1464,27 @@ __device__ __forceinline__ void onepass_window_wg(unsigned char* smem, const One
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int ww = w0 + grp + u * 16;
-        if (ww < w1) {
-            if (vfresh && ww == w_len - 1 && first_hb)   // store the new value row (:309)
-                reinterpret_cast<uint4*>(vwin + (int64_t)ww * kD)[sub] = vv[u].u;
+        if (ww < w1 && vfresh && ww == w_len - 1 && first_hb)   // store the new value row (:309)
+            reinterpret_cast<uint4*>(vwin + (int64_t)ww * kD)[sub] = vv[u].u;
+    }
+    // one head at a time (8 accumulators live, not 8 G: this path must not set the register allocation of the kernel)
+#pragma unroll 1
+    for (int h = 0; h < G; h++) {
+        float acc[8];
 #pragma unroll
-            for (int h = 0; h < G; h++) {
+        for (int j = 0; j < 8; j++) acc[j] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int ww = w0 + grp + u * 16;
+            if (ww < w1) {
                 const float pw = xs[h * 64 + (ww - w0)];
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc[h][j] = __builtin_fmaf(pw, (float)vv[u].h[j], acc[h][j]);
+                for (int j = 0; j < 8; j++) acc[j] = __builtin_fmaf(pw, (float)vv[u].h[j], acc[j]);
             }
         }
-    }
-#pragma unroll
-    for (int h = 0; h < G; h++) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; j++) red[grp * kRedLd + sub * 8 + j] = acc[h][j];
+        for (int j = 0; j < 8; j++) red[grp * kRedLd + sub * 8 + j] = acc[j];
         __syncthreads();
         if (tid < kD) {
             float sum = 0.f;
@@ -1561,13 +1567,18 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
             const float m_new = fmaxf(m_run[h], wave_max(x));
             alpha[h] = __expf(m_run[h] - m_new);              // 0 for the first block (m_run = -inf)
             const h16 e = (h16)__expf(x - m_new);
-            erow[(int64_t)h * a.ld + tb * 64 + lane] = e;
+            if constexpr (MF && G == 4) {
+                // matrix-pipe engine: e goes straight into the wave's LDS coefficient table [head][token] -- no memory round trip
+                *reinterpret_cast<h16*>(ptab + h * kValTabStride + lane * 2) = e;
+            } else {
+                erow[(int64_t)h * a.ld + tb * 64 + lane] = e;
+            }
             l_lane[h] = l_lane[h] * alpha[h] + (float)e;
             m_run[h] = m_new;
         }
-        // the value phase reads the e segments back as coefficients (scalar loads / one vector load into the per-wave
-        // table): after the stores have reached L2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // VALU engine: the value phase reads the e segments back as coefficients through scalar loads -- after the stores
+        // have reached L2
+        if constexpr (!(MF && G == 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     if constexpr (!PAIR) {
         for (int tb = tb0 + wave; tb < tb_end; tb += kWaves) {
@@ -1579,14 +1590,7 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
             softmax_step(tb, s, alpha);
 #pragma unroll
             for (int h = 0; h < G; h++) { acc0[h] *= alpha[h]; acc1[h] *= alpha[h]; }
-            if constexpr (MF && G == 4) {
-                float b0[G], b1[G];
-                value_tokblks<G, MF, 0, 4, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, b0, b1, ptab);
-#pragma unroll
-                for (int h = 0; h < G; h++) { acc0[h] += b0[h]; acc1[h] += b1[h]; }
-            } else {
-                value_tokblks<G, MF, 0, 4, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
-            }
+            value_tokblks<G, MF, 0, 4, 1, MF && G == 4>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
         }
     } else {
         const int pair = wave >> 1, odd = wave & 1;
@@ -1773,6 +1777,15 @@ inline int onepass_enabled()
         g_onepass = (e && e[0] == '0') ? 0 : 1;
     }
     return g_onepass;
+}
+int g_onepass_wgs = -1;   // MUSTAFAR_ONEPASS_WGS=n overrides the workgroup target of the one-pass launch
+inline int onepass_target_wgs(bool pair)
+{
+    if (g_onepass_wgs < 0) {
+        const char* e = getenv("MUSTAFAR_ONEPASS_WGS");
+        g_onepass_wgs = e ? atoi(e) : 0;
+    }
+    return g_onepass_wgs > 0 ? g_onepass_wgs : (pair ? 4096 : 1280);   // (sweeps at c3: VALU pair form flat from 4096 up; matrix-pipe engine best at 1024-1536)
 }
 int g_engine = -1;
 inline int fma_engine()
@@ -1969,7 +1982,9 @@ int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value
 {
     (void)T; (void)num_key_value_groups;   // token-chunk slabs + the window workgroups' slabs (one-pass form: 64-token window
     // chunks and a (max, sum) pair per slab and row)
-    return (int64_t)((Split_K < 1 ? 1 : Split_K) + kMaxWindow / kOneWinChunk) * Batch_Size * (kD + 2) * (int64_t)sizeof(float);
+    const int ntb = T > 0 ? T / 64 : 1;
+    const int slabs = (Split_K < 1 ? 1 : Split_K) > (ntb + 1) / 2 ? (Split_K < 1 ? 1 : Split_K) : (ntb + 1) / 2;   // one-pass: at most a slab per 2 blocks
+    return (int64_t)(slabs + kMaxWindow / kOneWinChunk) * Batch_Size * (kD + 2) * (int64_t)sizeof(float);
 }
 
 }  // extern "C"
@@ -2011,8 +2026,12 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
         const int ntb = T / 64;
         const bool pair = !fma_engine() || G != 4;                      // two waves per block unless the matrix-pipe engine runs
         const int round = pair ? kWaves / 2 : kWaves;                     // token blocks a workgroup has in flight
-        int tb_per_wg = (ntb + Split_K - 1) / Split_K;
-        tb_per_wg = (tb_per_wg + round - 1) / round * round;             // whole rounds of the 4 waves
+        // workgroups of the SpMV part: ~onepass_target_wgs(), every workgroup whole rounds of its waves (Split_K only sizes the
+        // workspace here: the slab count below never exceeds it by more than the rounding)
+        (void)Split_K;
+        const int want = (onepass_target_wgs(pair) + gy - 1) / gy;
+        int tb_per_wg = (ntb + want - 1) / want;
+        tb_per_wg = (tb_per_wg + round - 1) / round * round;
         const int S1 = (ntb + tb_per_wg - 1) / tb_per_wg;
         const int nchunks = (window_capacity + kOneWinChunk - 1) / kOneWinChunk;
         if (S1 + nchunks <= kMaxSlabs) {
