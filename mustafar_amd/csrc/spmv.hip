@@ -1767,17 +1767,23 @@ inline bool window_rows_last(int side)
     }
     return (g_window_last >> side) & 1;
 }
-// Structure of the fused decode entry point: 1 = one-pass launch (decode_onepass_kernel + onepass_finish_kernel; default),
-// 0 = key SpMV -> softmax rows -> value SpMV -> sum (MUSTAFAR_ONEPASS=0 / mustafar_set_onepass(0)).
+// Structure of the fused decode entry point: 1 = one-pass launch (decode_onepass_kernel + onepass_finish_kernel),
+// 0 = key SpMV -> softmax rows -> value SpMV -> sum, 2 = by size (default).  MUSTAFAR_ONEPASS=0|1|auto, mustafar_set_onepass().
+// Measured (round 2, fused + graph, tokens/s one-pass vs two-launch): c2 1566 vs 1282, c3 3970 vs 3890 (matrix-pipe engine
+// 5076 vs 4586), c4 1211 vs 1281 (1610 vs 1536), c5 2533 vs 2824 (2914 vs 3482): the one-pass launch saves the softmax launch,
+// a boundary and a ramp, which is what counts while a launch is tens of microseconds; its waves carry the state of both
+// phases (fewer of them fit) and it loses once the launches are long.  `by size` = kv-heads x compressed tokens below a
+// threshold per engine.
 int g_onepass = -1;
-inline int onepass_enabled()
+inline int onepass_mode()
 {
     if (g_onepass < 0) {
         const char* e = getenv("MUSTAFAR_ONEPASS");
-        g_onepass = (e && e[0] == '0') ? 0 : 1;
+        g_onepass = !e ? 2 : e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
     }
     return g_onepass;
 }
+inline bool onepass_enabled(int64_t kv_heads, int T);
 int g_onepass_wgs = -1;   // MUSTAFAR_ONEPASS_WGS=n overrides the workgroup target of the one-pass launch
 inline int onepass_target_wgs(bool pair)
 {
@@ -1795,6 +1801,13 @@ inline int fma_engine()
         g_engine = (e && (e[0] == 'm' || e[0] == 'M' || e[0] == '1')) ? 1 : 0;
     }
     return g_engine;
+}
+
+inline bool onepass_enabled(int64_t kv_heads, int T)
+{
+    const int mode = onepass_mode();
+    if (mode != 2) return mode == 1;
+    return kv_heads * T <= (fma_engine() ? 1250000 : 768000);   // c2, c3 (and c4 on the matrix-pipe engine) one-pass; c5 two launches
 }
 
 // Optional live timing of the two SpMV kernels inside mustafar_decode_attention (bench.py's roofline leg): HIP
@@ -2021,7 +2034,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     auto knew = static_cast<const h16*>(k_new);
     auto vnew = static_cast<const h16*>(v_new);
     const float inv_sqrt_d0 = (float)(1.0 / (double)sqrt_d);
-    if (T > 0 && onepass_enabled() && (ld_scores & 31) == 0) {
+    if (T > 0 && onepass_enabled(Batch_Size / groups, T) && (ld_scores & 31) == 0) {
         // ---- one-pass form: every wave runs key phase -> softmax step -> value phase on its token blocks; slabs merged per row
         const int ntb = T / 64;
         const bool pair = !fma_engine() || G != 4;                      // two waves per block unless the matrix-pipe engine runs
@@ -2198,14 +2211,14 @@ int mustafar_set_fma_engine(int engine)
 
 int mustafar_get_fma_engine(void) { return fma_engine(); }
 
-int mustafar_set_onepass(int enabled)
+int mustafar_set_onepass(int mode)
 {
-    if (enabled != 0 && enabled != 1) return MUSTAFAR_EINVAL;
-    g_onepass = enabled;
+    if (mode < 0 || mode > 2) return MUSTAFAR_EINVAL;
+    g_onepass = mode;
     return 0;
 }
 
-int mustafar_get_onepass(void) { return onepass_enabled(); }
+int mustafar_get_onepass(void) { return onepass_mode(); }
 
 #ifdef MUSTAFAR_WAVE_TRACE
 // Tool-only (tools/wave_trace.py): records go to `buf` (4 x u64 each, `cap` slots; zero it first).

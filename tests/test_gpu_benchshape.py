@@ -82,8 +82,19 @@ def _new(batch, Hq, Hkv):
             torch.randn(batch, Hkv, 1, 128, device=DEV).half())
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
-def test_fused_arena_eager_and_graph_at_bench_shape(name):
+@pytest.mark.parametrize("name,structure", [("c2", 2), ("c3", 2), ("c4", 2), ("c5", 2), ("c3", 0), ("c5", 1)])
+def test_fused_arena_eager_and_graph_at_bench_shape(name, structure):
+    """structure 2 = the library's own choice by size (one-pass launch at c2 / c3, two launches at c4 / c5); the other
+    structure is forced once at c3 and c5."""
+    from mustafar_amd import _lib
+    assert _lib.load().mustafar_set_onepass(structure) == 0
+    try:
+        _fused_arena_eager_and_graph(name)
+    finally:
+        _lib.load().mustafar_set_onepass(2)
+
+
+def _fused_arena_eager_and_graph(name):
     from mustafar_amd import _lib
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
     attn, cfg, past, ref, (Hq, Hkv, batch, T) = _setup(name)

@@ -34,9 +34,20 @@ def _left_padding_mask(bsz, kv_len, pads):
     return m
 
 
+@pytest.fixture
+def structure(request):
+    """Both structures of the fused entry point take the mask: the one-pass launch (1) and the two-launch form (0)."""
+    from mustafar_amd import _lib
+    lib = _lib.load()
+    assert lib.mustafar_set_onepass(request.param) == 0
+    yield request.param
+    assert lib.mustafar_set_onepass(2) == 0
+
+
+@pytest.mark.parametrize("structure", [0, 1], indirect=True)
 @pytest.mark.parametrize("arena", [False, True])
 @pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4)])
-def test_fused_decode_with_left_padding_mask(arena, hq, hkv):
+def test_fused_decode_with_left_padding_mask(arena, hq, hkv, structure):
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
     torch.manual_seed(3)
     bsz, D, L0, steps = 3, 128, 300, 9
@@ -81,7 +92,8 @@ def test_mask_shape_errors_match_the_reference():
         attn.decode(q, kn, vn, past, attention_mask=torch.zeros((1, 1, 1, 301), dtype=torch.float32, device=DEV))
 
 
-def test_masked_decode_with_rows_longer_than_32768():
+@pytest.mark.parametrize("structure", [0, 1], indirect=True)
+def test_masked_decode_with_rows_longer_than_32768(structure):
     """The streaming softmax form (T > 32768) applies the mask too."""
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
     torch.manual_seed(5)
@@ -98,7 +110,8 @@ def test_masked_decode_with_rows_longer_than_32768():
     torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
 
 
-def test_masked_decode_under_graph_replay():
+@pytest.mark.parametrize("structure", [0, 1], indirect=True)
+def test_masked_decode_under_graph_replay(structure):
     """A captured step with a mask buffer as wide as the window capacity: each replay reads kv_len columns."""
     from mustafar_amd import _lib
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
