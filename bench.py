@@ -52,7 +52,8 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is
 D, R = 128, 32
 
 API_NOTE = {
-    "fused": "mustafar_decode_attention (C ABI extension): key SpMV (+ window scores) -> softmax -> value SpMV (+ window p.V partials) -> sum, one call per layer",
+    "fused": "mustafar_decode_attention (C ABI extension), one call per layer; structure chosen by size: one-pass launch (key phase -> softmax step -> "
+             "value phase per 64-token block, slabs merged per row) or key SpMV (+ window scores) -> softmax -> value SpMV (+ window p.V partials) -> sum",
     "native": "the two reference entry points with un-padded (N=1) operands and a flat stream; PyTorch glue between them",
     "reference": "exact reference call sequence: q/p zero-padded to 8 rows, torch.cat of per-head streams per call, 8-row outputs, PyTorch glue",
 }
@@ -506,7 +507,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": label, "id": a.config, "layers": a.layers, "q_heads": Hq, "kv_heads": Hkv, "head_dim": D,
                    "sparsity": s, "seq_len": L, "compressed_tokens": T, "batch_per_gpu": batch, "residual_length": R,
-                   "api": a.api, "api_note": API_NOTE[a.api] + ("; the whole step captured once in a hipGraph and replayed" if use_graph else ""),
+                   "api": a.api, "api_note": API_NOTE[a.api] + ("; the whole step captured once in a hipGraph and replayed" if use_graph else "") + ("; structure run: " + roofline["kernel"] if a.api == "fused" else ""),
                    "fma_engine": "valu (v_fma_mix_f32; MFMA off)", "parallelism": f"replicas x{world}"},
         "self_check": {"passed": True, "excess_over_fp16_bound": round(excess, 3),
                        "what": "every layer's output of the timed call sequence (fused entry point, arena cache) vs the two reference entry "

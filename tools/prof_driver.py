@@ -25,3 +25,20 @@ for i in range(iters):
     mp.mustafar_key_formulation(*kcs[i % ncopies], q, T, 128, BH, groups)
     mp.mustafar_value_formulation(*vcs[i % ncopies], p, ws, 128, T, BH, groups)
 torch.cuda.synchronize()
+# PROF_FUSED=1: also the fused entry point in the structure the library picks at this size (one-pass launch at c2 / c3)
+if os.environ.get("PROF_FUSED") != "1":
+    sys.exit(0)
+from mustafar_amd.hook import MustafarAttention, MustafarConfig
+attn = MustafarAttention(MustafarConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, k_sparsity=s, v_sparsity=s, api="fused", arena=True))
+states = []
+for i in range(min(ncopies, 3)):
+    K = torch.randn(batch, Hkv, L, 128, device=dev, generator=gen).half()
+    V = torch.randn(batch, Hkv, L, 128, device=dev, generator=gen).half()
+    states.append(attn.to_fused(attn.build_cache(K, V)))
+    del K, V
+qn, kn, vn = (torch.randn(batch, h, 1, 128, device=dev, generator=gen).half() for h in (Hq, Hkv, Hkv))
+for i in range(iters):
+    calib_out = calib.clone()
+    p = states[i % len(states)]
+    attn.decode_fused(qn, kn, vn, (p[0], p[1].clone(), p[2], p[3].clone(), p[4], p[5]))
+torch.cuda.synchronize()
