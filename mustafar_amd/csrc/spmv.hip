@@ -1351,6 +1351,12 @@ __device__ __forceinline__ float wave_max(float v)
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+// A wave-uniform float kept in a scalar register (a running maximum, a rescale factor): VGPRs are what limits the
+// one-pass kernel's occupancy, and a spilled SGPR costs a lane of one shared VGPR.
+__device__ __forceinline__ float uniform_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -1503,7 +1509,7 @@ __device__ __forceinline__ void onepass_window_wg(unsigned char* smem, const One
 // VALU engine wants (its two-launch forms of the same grain: key 24.6 vs 25.8 us, value 29.5 vs 34.9 us at c3); the
 // matrix-pipe engine is faster with whole blocks.
 template <int G, bool MF, bool PAIR>
-__global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
+__global__ __launch_bounds__(kThreads, MF ? 5 : 1) void decode_onepass_kernel(   // (matrix-pipe form: 97 registers unbounded, one over the 5-wave step)
     const uint64_t* __restrict__ k_bmp, const unsigned char* __restrict__ k_nz, const uint32_t* __restrict__ k_idx,
     const uint32_t* __restrict__ k_nz_off, const uint64_t* __restrict__ v_bmp, const unsigned char* __restrict__ v_nz,
     const uint32_t* __restrict__ v_idx, const uint32_t* __restrict__ v_nz_off, OneArgs a, int64_t k_bmp_stride,
@@ -1552,7 +1558,7 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
     }
 
     static_assert(!(MF && PAIR), "the matrix-pipe engine runs whole blocks per wave");
-    float m_run[G], l_lane[G], acc0[G], acc1[G];
+    float m_run[G], l_lane[G], acc0[G], acc1[G];   // (m_run, l_lane: wave-uniform, in scalar registers)
 #pragma unroll
     for (int h = 0; h < G; h++) { m_run[h] = -INFINITY; l_lane[h] = 0.f; acc0[h] = 0.f; acc1[h] = 0.f; }
     // softmax step of one block on the lanes' scores s[] (lane = token): running maximum, e -> the score scratch, running
@@ -1564,8 +1570,8 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
         for (int h = 0; h < G; h++) {
             float x = scaled((h16)s[h], a.inv_sqrt_d);        // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
             if (mrow) x = masked(x, mk);
-            const float m_new = fmaxf(m_run[h], wave_max(x));
-            alpha[h] = __expf(m_run[h] - m_new);              // 0 for the first block (m_run = -inf)
+            const float m_new = uniform_f(fmaxf(m_run[h], wave_max(x)));
+            alpha[h] = uniform_f(__expf(m_run[h] - m_new));   // 0 for the first block (m_run = -inf)
             const h16 e = (h16)__expf(x - m_new);
             if constexpr (MF && G == 4) {
                 // matrix-pipe engine: e goes straight into the wave's LDS coefficient table [head][token] -- no memory round trip
@@ -1573,7 +1579,7 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
             } else {
                 erow[(int64_t)h * a.ld + tb * 64 + lane] = e;
             }
-            l_lane[h] = l_lane[h] * alpha[h] + (float)e;
+            l_lane[h] = uniform_f(l_lane[h] * alpha[h] + wave_sum((float)e));   // (the running sum of the wave, uniform)
             m_run[h] = m_new;
         }
         // VALU engine: the value phase reads the e segments back as coefficients through scalar loads -- after the stores
@@ -1663,7 +1669,7 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_kernel(
 #pragma unroll
         for (int w = 1; w < kWaves; w++) M = fmaxf(M, s_m[w * G + h]);
         const float scale = (mw == -INFINITY) ? 0.f : __expf(mw - M);   // a wave without blocks weighs nothing
-        const float l = wave_sum(l_lane[h]) * scale;
+        const float l = l_lane[h] * scale;
         if (lane == 0) s_l[wave * G + h] = l;
         red[(wave * 2 * G + h) * 64 + lane]     = acc0[h] * scale;
         red[(wave * 2 * G + G + h) * 64 + lane] = acc1[h] * scale;
