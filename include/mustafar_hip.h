@@ -204,8 +204,8 @@ int mustafar_get_fma_engine(void);
  * Structure of mustafar_decode_attention{,_view}: 1 = one-pass launch -- every wave runs key phase, softmax step and value
  * phase on its 64-token blocks and leaves (max, sum, unnormalised output) slabs that a row kernel merges (flash-decoding over
  * the compressed cache; needs ld_scores % 32 == 0, otherwise the other form runs); 0 = the round-1 form, key SpMV -> softmax
- * rows -> value SpMV -> sum; 2 (default) = by size: one-pass while kv-heads x compressed tokens is small (launches of tens of
- * microseconds: c2, c3), two launches beyond (c5).  Also MUSTAFAR_ONEPASS=0|1|auto in the environment.  Same inputs, same
+ * rows -> value SpMV -> sum; 2 (default) = by size: VALU engine one-pass while kv-heads x compressed tokens is small (launches
+ * of tens of microseconds: c2, c3), two launches beyond (c4, c5); matrix-pipe engine one-pass at every size.  Also MUSTAFAR_ONEPASS=0|1|auto in the environment.  Same inputs, same
  * outputs within fp16 (the one-pass form normalises in fp32 at the end instead of rounding the probabilities to fp16).
  */
 int mustafar_set_onepass(int mode);

@@ -1775,11 +1775,11 @@ inline bool window_rows_last(int side)
 }
 // Structure of the fused decode entry point: 1 = one-pass launch (decode_onepass_kernel + onepass_finish_kernel),
 // 0 = key SpMV -> softmax rows -> value SpMV -> sum, 2 = by size (default).  MUSTAFAR_ONEPASS=0|1|auto, mustafar_set_onepass().
-// Measured (round 2, fused + graph, tokens/s one-pass vs two-launch): c2 1566 vs 1282, c3 3970 vs 3890 (matrix-pipe engine
-// 5076 vs 4586), c4 1211 vs 1281 (1610 vs 1536), c5 2533 vs 2824 (2914 vs 3482): the one-pass launch saves the softmax launch,
-// a boundary and a ramp, which is what counts while a launch is tens of microseconds; its waves carry the state of both
-// phases (fewer of them fit) and it loses once the launches are long.  `by size` = kv-heads x compressed tokens below a
-// threshold per engine.
+// Measured (round 2, fused + graph, tokens/s one-pass vs two-launch).  VALU engine: c2 1566 vs 1282, c3 3970 vs 3890,
+// c4 1194 vs 1285, c5 2561 vs 2819 -- the one-pass launch saves the softmax launch, a boundary and a ramp, which is what
+// counts while a launch is tens of microseconds, and loses once the launches are long (its pair form pays two barriers per
+// block).  Matrix-pipe engine (e stays in LDS, no barriers): c3 5200 vs 4590, c4 1676 vs 1543, c5 3672 vs 3391 -- one-pass
+// at every size.  `by size` = that rule.
 int g_onepass = -1;
 inline int onepass_mode()
 {
@@ -1797,7 +1797,7 @@ inline int onepass_target_wgs(bool pair)
         const char* e = getenv("MUSTAFAR_ONEPASS_WGS");
         g_onepass_wgs = e ? atoi(e) : 0;
     }
-    return g_onepass_wgs > 0 ? g_onepass_wgs : (pair ? 4096 : 1280);   // (sweeps at c3: VALU pair form flat from 4096 up; matrix-pipe engine best at 1024-1536)
+    return g_onepass_wgs > 0 ? g_onepass_wgs : (pair ? 4096 : 0);   // (VALU pair form: flat from 4096 workgroups up at c3; 0: fixed blocks per workgroup)
 }
 int g_engine = -1;
 inline int fma_engine()
@@ -1813,7 +1813,7 @@ inline bool onepass_enabled(int64_t kv_heads, int T)
 {
     const int mode = onepass_mode();
     if (mode != 2) return mode == 1;
-    return kv_heads * T <= (fma_engine() ? 1250000 : 768000);   // c2, c3 (and c4 on the matrix-pipe engine) one-pass; c5 two launches
+    return fma_engine() || kv_heads * T <= 768000;   // VALU engine: c2, c3 one-pass, c4 / c5 two launches; matrix-pipe engine: always one-pass
 }
 
 // Optional live timing of the two SpMV kernels inside mustafar_decode_attention (bench.py's roofline leg): HIP
@@ -2048,8 +2048,13 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
         // workgroups of the SpMV part: ~onepass_target_wgs(), every workgroup whole rounds of its waves (Split_K only sizes the
         // workspace here: the slab count below never exceeds it by more than the rounding)
         (void)Split_K;
-        const int want = (onepass_target_wgs(pair) + gy - 1) / gy;
-        int tb_per_wg = (ntb + want - 1) / want;
+        int tb_per_wg;
+        if (onepass_target_wgs(pair) > 0) {
+            const int want = (onepass_target_wgs(pair) + gy - 1) / gy;
+            tb_per_wg = (ntb + want - 1) / want;
+        } else {
+            tb_per_wg = 8;   // matrix-pipe form: two whole blocks per wave at every size (sweeps at c3 / c4 / c5: 1024 / 2048-4096 / 4096 workgroups)
+        }
         tb_per_wg = (tb_per_wg + round - 1) / round * round;
         const int S1 = (ntb + tb_per_wg - 1) / tb_per_wg;
         const int nchunks = (window_capacity + kOneWinChunk - 1) / kOneWinChunk;
