@@ -7,7 +7,10 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <map>
+#include <mutex>
 #include <stdexcept>
+#include <utility>
 
 #include "../../include/mustafar_hip.h"
 
@@ -82,13 +85,18 @@ torch::Tensor mustafar_value_formulation(torch::Tensor bmp, torch::Tensor NZ, to
     c10::hip::HIPGuardMasqueradingAsCUDA guard(B.device());   // PyTorch-ROCm presents HIP devices as "cuda"
     const int split = mustafar_value_pick_split_k(M_Global, N, K_Global, Batch_Size, num_key_value_groups);
     const int64_t need = mustafar_value_workspace_bytes(M_Global, N, K_Global, Batch_Size, num_key_value_groups, split);
-    // fp32 partial slabs of THIS call, from the caching allocator like the output (the reference allocates per call too,
-    // mustafar_wrapper.cu:81/:202): stream-ordered reuse, nothing shared between streams or threads
-    torch::Tensor slabs;
+    // fp32 partial slabs: one buffer per (device, stream) -- launches of a stream run in order and may share it; different
+    // streams (or threads on different streams) never share slabs
     void* ws = nullptr;
     if (need > 0) {
-        slabs = torch::empty({need}, torch::TensorOptions().dtype(torch::kUInt8).device(B.device()));
-        ws = slabs.data_ptr();
+        auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
+        static std::mutex mu;
+        static std::map<std::pair<int, void*>, torch::Tensor> slabs;
+        std::lock_guard<std::mutex> lock(mu);
+        auto& t = slabs[{(int)B.device().index(), (void*)stream.stream()}];
+        if (!t.defined() || t.numel() < need)
+            t = torch::empty({std::max<int64_t>(need, 1 << 20)}, torch::TensorOptions().dtype(torch::kUInt8).device(B.device()));
+        ws = t.data_ptr();
     }
     auto C = torch::empty({Batch_Size, N, M_Global}, B.options());
     const int err = Value_SplitK_API(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(), nullptr,

@@ -87,11 +87,18 @@ def mustafar_key_formulation(bmp, NZ, idx, NZ_Offset, B, M_Global: int, K_Global
     return C
 
 
+_workspaces = {}   # (device, stream) -> slab buffer
+
+
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """fp32 partial slabs of ONE call, from torch's caching allocator like the reference's per-call output
-    (mustafar_wrapper.cu:81): the allocator hands a block back only to later work of the same stream, so calls on
-    different streams (or threads) never share slabs -- a process-wide buffer did."""
-    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    """fp32 partial slabs, one buffer per (device, STREAM): launches of one stream run in order, so they may share it;
+    two streams (or threads on different streams) never see each other's slabs -- a process-wide buffer did."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
 
 
 def mustafar_value_formulation(bmp, NZ, idx, NZ_Offset, B, Reduction_Workspace, M_Global: int, K_Global: int,
@@ -111,7 +118,7 @@ def mustafar_value_formulation(bmp, NZ, idx, NZ_Offset, B, Reduction_Workspace, 
     if split_k <= 0:
         split_k = L.mustafar_value_pick_split_k(M_Global, N, K_Global, Batch_Size, num_key_value_groups)
     nbytes = L.mustafar_value_workspace_bytes(M_Global, N, K_Global, Batch_Size, num_key_value_groups, split_k)
-    ws = _workspace(B.device, nbytes) if nbytes else None   # (kept alive until the launches below are enqueued)
+    ws = _workspace(B.device, nbytes) if nbytes else None
     ws_ptr = ws.data_ptr() if ws is not None else None
     C = torch.empty((Batch_Size, N, M_Global), dtype=torch.float16, device=B.device)
     with torch.cuda.device(B.device):

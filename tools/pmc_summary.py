@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output (kernel trace and/or --pmc counter collection) per kernel name.
 
-    python tools/pmc_summary.py <dir> [--match spmv]
+    python tools/pmc_summary.py <dir> [--match "spmv|onepass"]   (any of the |-separated substrings)
 """
 import argparse
 import collections
@@ -20,9 +20,9 @@ def main():
         cnt = collections.defaultdict(lambda: collections.defaultdict(int))
         for row in csv.DictReader(open(path)):
             k = row.get("Kernel_Name", "")
-            if a.match and a.match not in k:
+            if a.match and not any(m in k for m in a.match.split("|")):
                 continue
-            k = k.split("(")[0][:60]
+            k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             cnt[k][row["Counter_Name"]] += 1
         print("==", path)
@@ -34,9 +34,9 @@ def main():
         dur = collections.defaultdict(list)
         for row in csv.DictReader(open(path)):
             k = row.get("Kernel_Name", "")
-            if a.match and a.match not in k:
+            if a.match and not any(m in k for m in a.match.split("|")):
                 continue
-            dur[k.split("(")[0][:60]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+            dur[k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
         print("==", path)
         for k, v in dur.items():
             v.sort()
