@@ -234,13 +234,17 @@ class MustafarAttention:
         return (k_c, k_w, v_c, v_w, C, L + n)
 
     def _scratch(self, device, BH, ld, ws_bytes):
-        sc = getattr(self, "_scores", None)
-        if sc is None or sc.device != device or sc.numel() < BH * ld:
-            self._scores = torch.empty(BH * ld, dtype=torch.float16, device=device)
-        ws = getattr(self, "_ws_fused", None)
-        if ws is None or ws.device != device or ws.numel() < ws_bytes:
-            self._ws_fused = torch.empty(max(ws_bytes, 1 << 20), dtype=torch.uint8, device=device)
-        return self._scores, self._ws_fused
+        """Score scratch and slab workspace of the fused entry point, one pair per (device, stream): calls on different
+        streams may overlap, calls on one stream cannot."""
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        pool = self.__dict__.setdefault("_fused_scratch", {})
+        sc, ws = pool.get(key, (None, None))
+        if sc is None or sc.numel() < BH * ld:
+            sc = torch.empty(BH * ld, dtype=torch.float16, device=device)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = torch.empty(max(ws_bytes, 1 << 20), dtype=torch.uint8, device=device)
+        pool[key] = (sc, ws)
+        return sc, ws
 
     def decode_fused(self, query_states, key_states, value_states, past, step_counter: Optional[torch.Tensor] = None,
                      attention_mask: Optional[torch.Tensor] = None):
