@@ -374,6 +374,19 @@ def run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib):
            "steps": steps, "self_check_excess": round(excess, 3),
            "kernel": rl["kernel"], "kernel_us": rl["avg_launch_us"], "roofline_frac": rl["frac"], "roofline_achieved_GBps": rl["achieved"], "kv_bytes_reference_layout": int(w.ref_kv_bytes), "dense_kv_bytes": int(w.dense_bytes),
            "arena_bytes_in_use": w.extra.get("arena_bytes_in_use"), "arena_bytes_reserved": w.extra.get("arena_bytes_reserved")}
+    if (w.Hq // w.Hkv) % 4 == 0:   # the same leg on the matrix-pipe engine (opt-in; GQA-4 kernels only)
+        from mustafar_amd import _lib
+        _lib.check(lib.mustafar_set_fma_engine(1), "set_fma_engine")
+        try:
+            ex = w.self_check()
+            if not ex <= 1.0:
+                raise SystemExit(f"bench.py: self-check FAILED at {name} on the MFMA engine: {ex:.2f}x the fp16 bound")
+            dt_e, (ku, vu, ne) = w.timed_graph(steps, 2)
+            rm = w.roofline(ku, vu, ne, traffic_file=False)
+        finally:
+            _lib.check(lib.mustafar_set_fma_engine(0), "set_fma_engine")
+        out["fma_engine_mfma"] = {"value": round(world * w.batch * steps / dt_e, 2), "ms_per_step": round(dt_e / steps * 1e3, 4), "self_check_excess": round(ex, 3),
+                                  "kernel": rm["kernel"], "kernel_us": rm["avg_launch_us"], "roofline_frac": rm["frac"], "roofline_achieved_GBps": rm["achieved"]}
     del w
     torch.cuda.empty_cache()
     return out
