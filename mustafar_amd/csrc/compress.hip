@@ -12,6 +12,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/mustafar_hip.h"
 
@@ -387,6 +389,196 @@ __global__ __launch_bounds__(kThreads) void tile_pack_kernel(Side s0, Side s1, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------ one pass
+// Prune + compress + pack of a 64-token block in ONE read of it (the fused forms: mustafar_cache_append_kv).  Both passes
+// above are bound by vector instructions, not bytes (pass 1 ~5 800 per block, pass 2 ~3 200: 136 us per side at c3 against
+// 40 us of traffic), and pass 2 re-derives from memory what pass 1 had in registers.  Here one wave keeps the 64 raw rows
+// in registers from the load to the packed stream:
+//   threshold   as tile_meta_kernel (lane = row, guarded magnitudes beside the raw words: 16 KB of LDS per wave leave
+//               three waves per SIMD, so registers are not what is short)
+//   K           tile d = element d of the 64 rows: one ballot; the lane's own element goes to rank(lane) of the tile in an
+//               LDS image of the block's stream, the mask and the tile's start to lane d % 64 (v_writelane)
+//   V           tiles = the lane's own row halves: the lane walks its 128 flags and appends the kept values itself
+//   base        the stream position of the block = sum of the lengths of the blocks in front of it in the head.  Every
+//               block publishes its length as soon as it is known -- one 8-byte {length, valid} word, one sc1 store -- and
+//               reads the words of its predecessors (sc1 loads, polled).  Nobody waits before publishing, so the chain is one
+//               hop long whatever the number of blocks; workgroups are dispatched in linear order and a predecessor has a
+//               smaller linear id, so what a block waits for is running or done.  The poll is bounded all the same.
+//   flush       the LDS image (one contiguous range of the output) leaves as 16-byte stores
+constexpr int kSpinMax = 1 << 22;
+
+__device__ __forceinline__ void gran_publish(uint64_t* g, uint32_t len)
+{
+    __hip_atomic_store(g, (1ull << 32) | len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t gran_load(const uint64_t* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// K geometry: registers J .. 63 of the block.  f = keep flags of register J (bit 0 / bit 16), raw = its two halfs.
+// `run` = stream position (half2 units, inside the block) of the next tile: wave-uniform.
+template <int J>
+__device__ __forceinline__ void key_pack(const uint32_t (&f)[kD / 2], const uint32_t (&raw)[kD / 2], uint16_t* s_out, int lane, uint32_t& run,
+                                         uint32_t& a_lo, uint32_t& a_hi, uint32_t& b_lo, uint32_t& b_hi, uint32_t& sa, uint32_t& sb)
+{
+    if constexpr (J < kD / 2) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const bool kept = half ? (f[J] >> 16) != 0 : (f[J] & 1u) != 0;
+            const uint64_t m = __ballot(kept);                       // bit l <=> token l of the block has element 2J + half
+            const int cnt = __popcll(m), padded = (cnt + 7) & ~7;
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            uint16_t* tile = s_out + 2 * run;
+            if (kept) tile[rank] = (uint16_t)(half ? raw[J] >> 16 : raw[J]);
+            if (lane >= cnt && lane < padded) tile[lane] = 0;         // compression.py:309 relies on a pre-zeroed buffer
+            const uint64_t mr = __builtin_bitreverse64(m);            // as stored: MSB = element 0
+            constexpr int D = 2 * J;
+            if (half == 0) {
+                if constexpr (D < 64) { write_lane<D>(a_lo, (uint32_t)mr); write_lane<D>(a_hi, (uint32_t)(mr >> 32)); write_lane<D>(sa, run); }
+                else { write_lane<D - 64>(b_lo, (uint32_t)mr); write_lane<D - 64>(b_hi, (uint32_t)(mr >> 32)); write_lane<D - 64>(sb, run); }
+            } else {
+                if constexpr (D < 64) { write_lane<D + 1>(a_lo, (uint32_t)mr); write_lane<D + 1>(a_hi, (uint32_t)(mr >> 32)); write_lane<D + 1>(sa, run); }
+                else { write_lane<D - 63>(b_lo, (uint32_t)mr); write_lane<D - 63>(b_hi, (uint32_t)(mr >> 32)); write_lane<D - 63>(sb, run); }
+            }
+            run += padded >> 1;
+        }
+        key_pack<J + 1>(f, raw, s_out, lane, run, a_lo, a_hi, b_lo, b_hi, sa, sb);
+    }
+}
+
+// grid: x = token block, y = head, z = side; ONE wave.  gran: [sides][B'][ntb] words, zero at launch.  overflow: bit 0 = a
+// head outgrew its region (nothing of the offending blocks is written; the caller re-houses and repeats), bit 1 = a poll ran out.
+__global__ __launch_bounds__(64, 2) void compress_block_kernel(Side s0, Side s1, int ntb, uint64_t* __restrict__ gran, int32_t* __restrict__ overflow)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_out[64 * kD];   // the block's stream, worst case (nothing pruned)
+    const bool z = blockIdx.z != 0;
+    const uint16_t* x = z ? s1.x : s0.x;
+    const int64_t head_stride = z ? s1.head_stride : s0.head_stride;
+    int64_t* bmp = z ? s1.bmp : s0.bmp;
+    int32_t* accum = z ? s1.accum : s0.accum;
+    int64_t* totals = z ? s1.totals : s0.totals;
+    const uint32_t* nz_offset = z ? s1.nz_offset : s0.nz_offset;
+    uint16_t* nz = z ? s1.nz : s0.nz;
+    const Rows rows = z ? s1.rows : s0.rows;
+    const int64_t region = z ? s1.region_halfs : s0.region_halfs;
+    const int kth = z ? s1.kth : s0.kth;
+    const int key = z ? s1.key : s0.key;
+    const int lane = threadIdx.x, tb = blockIdx.x, h = blockIdx.y;
+    const uint32_t H = 0x80008000u, ONES = 0x00010001u;
+
+    const uint4* src = reinterpret_cast<const uint4*>(x + h * head_stride + ((int64_t)tb * 64 + lane) * kD);
+    uint32_t raw[kD / 2], w[kD / 2];
+#pragma unroll
+    for (int p = 0; p < kD / 8; p++) {
+        const uint4 v = src[p];
+        raw[4 * p] = v.x; raw[4 * p + 1] = v.y; raw[4 * p + 2] = v.z; raw[4 * p + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < kD / 2; j++) w[j] = raw[j] | H;   // magnitudes with the guard bits set
+    uint32_t thr = 0;   // 0 keeps everything (rows already pruned)
+    if (kth > 0) {
+#pragma unroll 1
+        for (int bit = 14; bit >= 0; bit--) {
+            const uint32_t c = thr | (1u << bit);
+            const uint32_t cc = c | (c << 16);
+            uint32_t ge = 0;
+#pragma unroll
+            for (int j = 0; j < kD / 2; j++) ge += ((w[j] - cc) >> 15) & ONES;
+            const int below = kD - (int)((ge & 0xffffu) + (ge >> 16));
+            if (below < kth) thr = c;
+        }
+    }
+    const uint32_t tt = thr | (thr << 16);
+#pragma unroll
+    for (int j = 0; j < kD / 2; j++) {   // w[j]: bit 0 / bit 16 set iff element 2j / 2j + 1 is kept and non-zero (-0.0 is zero)
+        const uint32_t keep = (w[j] - tt) >> 15;
+        const uint32_t nzf = ((w[j] & 0x7fff7fffu) + 0x7fff7fffu) >> 15;
+        w[j] = keep & nzf & ONES;
+    }
+    uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;   // masks of tiles lane and 64 + lane (MSB = element 0)
+    uint32_t sa = 0, sb = 0;                            // their starts inside the block, half2 units
+    uint32_t total = 0;                                 // the block's length, half2 units (wave-uniform)
+    if (key) {
+        key_pack<0>(w, raw, s_out, lane, total, a_lo, a_hi, b_lo, b_hi, sa, sb);
+    } else {
+#pragma unroll
+        for (int j = 0; j < kD / 2; j++) {
+            const uint32_t two = ((w[j] << 1) | (w[j] >> 16)) & 3u;   // (element 2j, element 2j + 1)
+            const int e = 2 * (j & 31);
+            uint32_t& word = (j < 32) ? (e < 32 ? a_hi : a_lo) : (e < 32 ? b_hi : b_lo);
+            word |= two << (30 - (e & 31));
+        }
+        const int na = __popc(a_lo) + __popc(a_hi), nb = __popc(b_lo) + __popc(b_hi);
+        const int32_t pa = ((na + 7) & ~7) >> 1, pb = ((nb + 7) & ~7) >> 1;   // compression.py:46-48
+        int32_t ca = pa, cb = pb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {   // inclusive scans over the lanes
+            const int32_t ua = __shfl_up(ca, o), ub = __shfl_up(cb, o);
+            if (lane >= o) { ca += ua; cb += ub; }
+        }
+        const int32_t tot_a = __shfl(ca, 63);
+        total = (uint32_t)(tot_a + __shfl(cb, 63));
+        sa = (uint32_t)(ca - pa);
+        sb = (uint32_t)(tot_a + cb - pb);
+        // the lane appends the kept values of its two tiles in element order, then the zeros up to the padded lengths
+        uint32_t cur = 2 * sa;   // halfs
+#pragma unroll
+        for (int j = 0; j < kD / 2; j++) {
+            if (j == 32) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) if (na + i < 2 * pa) s_out[cur + i] = 0;
+                cur = 2 * sb;
+            }
+            if (w[j] & 1u) s_out[cur] = (uint16_t)raw[j];
+            cur += w[j] & 1u;
+            if (w[j] >> 16) s_out[cur] = (uint16_t)(raw[j] >> 16);
+            cur += w[j] >> 16;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (nb + i < 2 * pb) s_out[cur + i] = 0;
+    }
+    // ---- publish the block's length, then collect the lengths in front of it
+    uint64_t* g = gran + ((int64_t)(z ? gridDim.y : 0) + h) * ntb;
+    if (lane == 0) gran_publish(g + tb, total);
+    int32_t* head_acc = accum + (int64_t)h * rows.idx_stride + rows.tile0;
+    uint32_t sum = 0;
+    bool failed = false;
+    for (int b0 = 0; b0 < tb; b0 += 64) {
+        const int b = b0 + lane;
+        if (b < tb) {
+            uint64_t v = gran_load(g + b);
+            for (int spin = 0; !(v >> 32) && spin < kSpinMax; spin++) {
+                __builtin_amdgcn_s_sleep(2);
+                v = gran_load(g + b);
+            }
+            failed |= !(v >> 32);
+            sum += (uint32_t)v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const uint32_t base = (rows.tile0 ? (uint32_t)head_acc[0] : 0u) + sum;   // (append: entry tile0 holds the head's length so far, model :352-360)
+    if (__ballot(failed)) {
+        if (lane == 0) atomicOr(overflow, 2);
+        return;
+    }
+    // ---- metadata of the block's 128 tiles: bitmaps, offsets (exclusive prefix over the whole head, compression.py:294-298)
+    int64_t* bmp_row = bmp + h * rows.bmp_stride + rows.tile0 + (int64_t)tb * kD;
+    int32_t* acc_row = head_acc + (int64_t)tb * kD;
+    bmp_row[lane] = (int64_t)(((uint64_t)a_hi << 32) | a_lo);
+    bmp_row[64 + lane] = (int64_t)(((uint64_t)b_hi << 32) | b_lo);
+    acc_row[lane] = (int32_t)(base + sa);          // (entry 0 of a block = entry 128 of the block in front: same value from both)
+    acc_row[64 + lane] = (int32_t)(base + sb);
+    if (lane == 0) acc_row[kD] = (int32_t)(base + total);
+    const int64_t end_halfs = 2 * (int64_t)(base + total);
+    if (tb == ntb - 1 && lane == 0) totals[h] = end_halfs;   // the head's new stream length (compression.py:302)
+    if (region > 0 && end_halfs > region) {   // a cache view whose region the head has outgrown: nothing beyond it is written
+        if (lane == 0 && overflow) atomicOr(overflow, 1);
+        return;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(nz + 8 * (int64_t)nz_offset[h] + 2 * (int64_t)base);
+    const int n16 = (int)(total >> 2);   // every tile is padded to 8 halfs = 16 bytes
+    for (int p = lane; p < n16; p += 64) dst[p] = reinterpret_cast<const uint4*>(s_out)[p];
+}
+
 // Move the rows [drop, len) of every head's window to the front (model :392-393 slices and clones; here in place).
 // One workgroup per (head, side); the rows that stay are read in full before any is written, so the ranges may overlap.
 __global__ __launch_bounds__(kThreads) void window_drop_front_kernel(uint16_t* k_win, uint16_t* v_win, int64_t head_stride, int len, int drop)
@@ -407,6 +599,13 @@ __global__ __launch_bounds__(kThreads) void window_drop_front_kernel(uint16_t* k
         const int p = threadIdx.x + i * kThreads;
         if (p < n16) dst[p] = v[i];
     }
+}
+
+// MUSTAFAR_COMPRESS=twopass keeps the round-2 two-pass form of the fused calls (pass 1 + scan + pass 2); default: one pass.
+inline bool one_pass_compress()
+{
+    static const int mode = [] { const char* e = getenv("MUSTAFAR_COMPRESS"); return (e && !strcmp(e, "twopass")) ? 0 : 1; }();
+    return mode != 0;
 }
 
 inline Rows fresh_rows(int t) { const int64_t tiles = (int64_t)t * kD / 64; return Rows{tiles, tiles + 1, 0}; }
@@ -562,7 +761,7 @@ int mustafar_cache_append_pack_value(void* stream, const void* x, int Bp, int t,
 int64_t mustafar_compress_scratch_bytes(int Bp, int t)
 {
     if (Bp < 1 || t < 64 || (t & 63)) return 0;
-    return 2 * (int64_t)Bp * (t / 64) * (int64_t)sizeof(int32_t);
+    return 2 * (int64_t)Bp * (t / 64) * (int64_t)sizeof(uint64_t);   // one length word per block and side (two-pass form: an int)
 }
 
 int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int64_t head_stride, int Bp, int t, int D, int kth_k,
@@ -581,6 +780,13 @@ int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int
          k_head_total, nullptr, k_dst->nz_offset, static_cast<uint16_t*>(k_dst->nz), kr, k_region_halfs, kth_k, 1},
         {static_cast<const uint16_t*>(v_x), head_stride, reinterpret_cast<int64_t*>(v_dst->bmp), reinterpret_cast<int32_t*>(v_dst->idx), nullptr,
          v_head_total, nullptr, v_dst->nz_offset, static_cast<uint16_t*>(v_dst->nz), vr, v_region_halfs, kth_v, 0}};
+    if (one_pass_compress()) {
+        const int ntb = t / 64;
+        const int err = (int)hipMemsetAsync(scratch, 0, 2 * (size_t)Bp * ntb * sizeof(uint64_t), st);   // the length words: not yet valid
+        if (err) return err;
+        compress_block_kernel<<<dim3(ntb, Bp, 2), 64, 0, st>>>(s[0], s[1], ntb, static_cast<uint64_t*>(scratch), overflow_flag);
+        return (int)hipGetLastError();
+    }
     const int err = launch_meta(st, s, 2, Bp, t, static_cast<int32_t*>(scratch), overflow_flag, false);
     if (err) return err;
     return launch_pack(st, s, 2, Bp, t, overflow_flag);
