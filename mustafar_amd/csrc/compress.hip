@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "../../include/mustafar_hip.h"
+#include "select_kth.h"
 
 namespace {
 
@@ -394,8 +395,9 @@ __global__ __launch_bounds__(kThreads) void tile_pack_kernel(Side s0, Side s1, i
 // above are bound by vector instructions, not bytes (pass 1 ~5 800 per block, pass 2 ~3 200: 136 us per side at c3 against
 // 40 us of traffic), and pass 2 re-derives from memory what pass 1 had in registers.  Here one wave keeps the 64 raw rows
 // in registers from the load to the packed stream:
-//   threshold   as tile_meta_kernel (lane = row, guarded magnitudes beside the raw words: 16 KB of LDS per wave leave
-//               three waves per SIMD, so registers are not what is short)
+//   threshold   lane = row, sliced by bit (select_kth.h): the 64 words of the row are transposed into bit planes and the
+//               k-th smallest magnitude is read off 128-bit candidate sets; 16 KB of LDS per wave leave two to three
+//               waves per SIMD, so the extra registers cost nothing
 //   K           tile d = element d of the 64 rows: one ballot; the lane's own element goes to rank(lane) of the tile in an
 //               LDS image of the block's stream, the mask and the tile's start to lane d % 64 (v_writelane)
 //   V           tiles = the lane's own row halves: the lane walks its 128 flags and appends the kept values itself
@@ -471,26 +473,14 @@ __global__ __launch_bounds__(64, 2) void compress_block_kernel(Side s0, Side s1,
         const uint4 v = src[p];
         raw[4 * p] = v.x; raw[4 * p + 1] = v.y; raw[4 * p + 2] = v.z; raw[4 * p + 3] = v.w;
     }
-#pragma unroll
-    for (int j = 0; j < kD / 2; j++) w[j] = raw[j] | H;   // magnitudes with the guard bits set
-    uint32_t thr = 0;   // 0 keeps everything (rows already pruned)
-    if (kth > 0) {
-#pragma unroll 1
-        for (int bit = 14; bit >= 0; bit--) {
-            const uint32_t c = thr | (1u << bit);
-            const uint32_t cc = c | (c << 16);
-            uint32_t ge = 0;
-#pragma unroll
-            for (int j = 0; j < kD / 2; j++) ge += ((w[j] - cc) >> 15) & ONES;
-            const int below = kD - (int)((ge & 0xffffu) + (ge >> 16));
-            if (below < kth) thr = c;
-        }
-    }
+    // k-th smallest magnitude of the lane's row, sliced by bit (select_kth.h: ~1 300 operations against the 3 840 of the
+    // search by value in tile_meta_kernel); 0 keeps everything (rows already pruned)
+    const uint32_t thr = kth > 0 ? kth_magnitude128(raw, kth) : 0u;
     const uint32_t tt = thr | (thr << 16);
 #pragma unroll
     for (int j = 0; j < kD / 2; j++) {   // w[j]: bit 0 / bit 16 set iff element 2j / 2j + 1 is kept and non-zero (-0.0 is zero)
-        const uint32_t keep = (w[j] - tt) >> 15;
-        const uint32_t nzf = ((w[j] & 0x7fff7fffu) + 0x7fff7fffu) >> 15;
+        const uint32_t keep = ((raw[j] | H) - tt) >> 15;                 // the guard bit of a half survives iff its magnitude >= thr
+        const uint32_t nzf = ((raw[j] & 0x7fff7fffu) + 0x7fff7fffu) >> 15;
         w[j] = keep & nzf & ONES;
     }
     uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;   // masks of tiles lane and 64 + lane (MSB = element 0)
