@@ -32,11 +32,11 @@ __device__ __forceinline__ bool nonzero_h(uint16_t v) { return (v & 0x7fffu) != 
 // non-NaN values, so thr is found bit by bit from the MSB: thr |= b  iff  fewer than k magnitudes are < (thr | b).
 //
 // Lane = row: one wave takes 64 rows, transposed through LDS (row stride 65 dwords: conflict-free both ways), and every
-// lane runs the 15-step search on its own row held in 64 VGPRs.  A count is a SWAR pass over the 64 packed pairs:
-// with the guard bit H = 0x8000 set in each half, (m | H) - (c | c << 16) keeps H in a half iff that magnitude >= c
-// (no borrow crosses the halves), and the set guard bits are tallied two 16-bit counters at a time.  4 plain VALU ops
-// per pair per step (sub, shift, and, add); the wave-per-row form spent ~12 SALU + 4 VALU per step and per ROW on ballots and was
-// instruction-bound at 1.7 TB/s.
+// lane finds the threshold of its own row held in 64 VGPRs (select_kth.h: bit planes + 128-bit candidate sets, ~1 300
+// operations per row-lane; round 1 searched by value, 15 steps x 64 words x 4 operations, and before that a wave per row
+// spent ~12 SALU + 4 VALU per step and per ROW on ballots and was instruction-bound at 1.7 TB/s).  Keep / prune is a SWAR
+// compare: with the guard bit H = 0x8000 set in each half, (m | H) - (thr | thr << 16) keeps H in a half iff that
+// magnitude >= thr (no borrow crosses the halves).
 constexpr int kPruneRows  = 64;            // rows per wave
 constexpr int kPruneLd    = kD / 2 + 1;    // LDS row stride in dwords
 
@@ -63,18 +63,8 @@ __global__ __launch_bounds__(64) void prune_magnitude_kernel(const uint32_t* __r
         uint32_t wh[kD / 2];   // magnitudes with the guard bits set (the signs stay behind in LDS)
 #pragma unroll
         for (int j = 0; j < kD / 2; j++) wh[j] = s_rows[lane * kPruneLd + j] | H;
-        // bit-by-bit search of the k-th smallest magnitude
-        uint32_t thr = 0;
-#pragma unroll 1
-        for (int bit = 14; bit >= 0; bit--) {
-            const uint32_t c = thr | (1u << bit);
-            const uint32_t cc = c | (c << 16);
-            uint32_t ge = 0;   // two 16-bit counters: magnitudes >= c among the low / high halves
-#pragma unroll
-            for (int j = 0; j < kD / 2; j++) ge += ((wh[j] - cc) >> 15) & ONES;
-            const int below = kD - (int)((ge & 0xffffu) + (ge >> 16));
-            if (below < kth) thr = c;
-        }
+        // k-th smallest magnitude, sliced by bit (select_kth.h; the guard bits sit where the planes are not read)
+        const uint32_t thr = kth_magnitude128(wh, kth);
         // keep |x| >= thr, else the sign bit alone
         const uint32_t tt = thr | (thr << 16);
 #pragma unroll
