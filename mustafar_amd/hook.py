@@ -239,10 +239,15 @@ class MustafarAttention:
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
         pool = self.__dict__.setdefault("_fused_scratch", {})
         sc, ws = pool.get(key, (None, None))
+        # Grown with headroom (two more 256-token triggers) and never freed while this object lives: a captured graph of an
+        # earlier call keeps the old addresses (bench.py captures the graph of the NEXT cache length while the current one is
+        # still being replayed).
         if sc is None or sc.numel() < BH * ld:
-            sc = torch.empty(BH * ld, dtype=torch.float16, device=device)
+            self.__dict__.setdefault("_retired_scratch", []).append(sc)
+            sc = torch.empty(BH * (ld + 512), dtype=torch.float16, device=device)
         if ws is None or ws.numel() < ws_bytes:
-            ws = torch.empty(max(ws_bytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.__dict__.setdefault("_retired_scratch", []).append(ws)
+            ws = torch.empty(max(ws_bytes + ws_bytes // 8, 1 << 20), dtype=torch.uint8, device=device)
         pool[key] = (sc, ws)
         return sc, ws
 
