@@ -38,7 +38,7 @@ def _rows():
     rows.append(np.zeros((3, 128), np.float16))
     rows.append(np.full((2, 128), -0.0, np.float16))
     rows.append((rng.standard_normal((50, 128)) * 1e-6).astype(np.float16))             # subnormals
-    big = rng.standard_normal((50, 128)).astype(np.float16) * np.float16(3e4)
+    big = rng.standard_normal((50, 128)).astype(np.float32) * 3e4
     rows.append(np.clip(big, -65504, 65504).astype(np.float16))                         # up to the largest finite magnitude
     one = np.zeros((4, 128), np.float16); one[:, 77] = 5.0
     rows.append(one)
