@@ -172,16 +172,19 @@ int mustafar_counter_add(void* stream, int32_t* counter, int delta);
 /*
  * The whole 256-token trigger of the hook (models/llama_mustafar_kernel.py:324-398) for K and V together, from the RAW
  * window rows: prune (:325-326, kth = max(1, int(sparsity * D)); 0 = rows already pruned), compress (:328-337) and append
- * (:339-390) in three launches -- pass 1 (thresholds in registers, bitmaps, counts) for both sides, one scan, pass 2 (pack
- * from the raw rows by the bitmaps) for both sides.  No pruned copy is written, nothing is allocated and nothing is read
- * back on the host, so the call can be captured in a hipGraph.  The same call compresses a prefill block (:416-437) into
- * two empty views (old_tokens = 0).
+ * (:339-390) in ONE launch behind a memset node: one wave per 64-token block keeps the rows in registers from the load to the
+ * packed stream (threshold, bitmaps, counts, pack), and the blocks of a head find their stream positions from each other's
+ * published lengths.  No pruned copy is written, nothing is allocated and nothing is read back on the host, so
+ * the call can be captured in a hipGraph.  The same call compresses a prefill block (:416-437) into two empty views
+ * (old_tokens = 0).  (MUSTAFAR_COMPRESS=twopass in the environment: the two-pass form, three launches.)
  *   k_x / v_x       fp16 rows of 128; head h starts `head_stride` elements after head h - 1 (a window buffer: capacity * 128)
  *   *_head_total    i64 [B'] out: every head's new stream length in halfs (read it whenever convenient, e.g. through an
  *                   asynchronous copy: the next append needs it only to decide about room)
  *   *_region_halfs  room of a head's stream region (0 = unchecked); overflow_flag (device int, may be NULL): set when a head
- *                   outgrows its region -- pass 2 then writes NOTHING (bitmaps / offsets of the new tokens are there, the
- *                   streams are not): re-house and repeat.  Callers keep room for one worst-case append (t * 128 halfs).
+ *                   outgrows its region (bit 0) -- the blocks that would cross the end of the region then write no stream
+ *                   bytes (bitmaps / offsets of the new tokens are there): re-house and repeat; bit 1: a block gave up
+ *                   waiting for the lengths in front of it (never seen; the poll is bounded so that every wave exits).
+ *                   Callers keep room for one worst-case append (t * 128 halfs).
  *   scratch         mustafar_compress_scratch_bytes(B', t) bytes
  */
 int64_t mustafar_compress_scratch_bytes(int Bp, int t);

@@ -139,7 +139,7 @@ class CompressedArena:
                            t: int, kth_k: int, kth_v: int) -> None:
         """k_rows / v_rows: fp16 [B, Hkv, >= t, 128] buffers (a window: rows [0, t) of every head are compressed; the row
         stride between heads is the buffer's) holding RAW (unpruned) tokens; kth = max(1, int(sparsity * 128)) (model :97),
-        0 for rows that are already pruned.  Three launches for both sides (mustafar_cache_append_kv), nothing allocated
+        0 for rows that are already pruned.  One launch for both sides (mustafar_cache_append_kv), nothing allocated
         on the device side of the call and nothing read back: room for one worst-case append (t * 128 halfs per head) is
         secured BEFORE the launches from the exact stream lengths of the previous append, which travel to the host through
         an asynchronous pinned-memory copy enqueued right behind it."""
@@ -190,7 +190,7 @@ class CompressedArena:
     def from_raw_pair(cls, k_rows: torch.Tensor, v_rows: torch.Tensor, t: int, kth_k: int, kth_v: int, cap_tokens: Optional[int] = None,
                       headroom: float = DEFAULT_HEADROOM):
         """Prefill (model :416-437): prune + compress the first t tokens of raw K / V [B, Hkv, L, 128] into two new arenas,
-        two reads of the dense block per side and no pruned copy.  The stream regions start from an estimate (kept values
+        one read of the dense block per side and no pruned copy.  The stream regions start from an estimate (kept values
         per token + padding, + 12 %) and are re-housed at the measured size."""
         heads = k_rows.shape[0] * k_rows.shape[1]
         cap = _round_up(cap_tokens if cap_tokens else t + DEFAULT_EXTRA_TOKENS, 256)

@@ -316,7 +316,7 @@ class MustafarAttention:
             kth_k = compression.kth_from_sparsity(cfg.k_sparsity, D)
             kth_v = compression.kth_from_sparsity(cfg.v_sparsity, D)
             if use_arena or (cfg.arena and C == 0):
-                # prune (:325-326) + compress + append (:328-390) of the raw window rows in three launches, no host read
+                # prune (:325-326) + compress + append (:328-390) of the raw window rows in one launch, no host read
                 if C == 0:
                     k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, 256 + cfg.arena_extra_tokens,
                                                              cfg.arena_headroom)
