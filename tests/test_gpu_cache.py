@@ -205,3 +205,90 @@ def test_fused_append_equals_the_two_call_form():
         fr, br = fused.to_reference(), b.to_reference()
         assert torch.equal(fr[0], br[0]) and torch.equal(fr[1], br[1]) and torch.equal(fr[3], br[3])
         assert torch.equal(torch.cat(fr[2]).view(torch.int16), torch.cat(br[2]).view(torch.int16))
+
+
+def test_fused_append_replays_from_a_captured_graph():
+    """mustafar_cache_append_kv (memset node + one launch) and the window slide captured in a hipGraph: nothing is allocated
+    and nothing is read back inside the call, so the replay appends whatever the window buffers hold at that moment.  The
+    graph writes behind the same 256 tokens every time it runs: replayed on two different windows, each result must equal
+    the eager call on the same data, bit for bit."""
+    import ctypes
+    from mustafar_amd import _lib, compression
+    from mustafar_amd.cache import CompressedArena
+    B, H, s = 2, 2, 0.7
+    kth = compression.kth_from_sparsity(s, 128)
+    L = _lib.load()
+    K0, V0 = _raw(B, H, 256, 71), _raw(B, H, 256, 72)
+
+    def fresh():
+        return CompressedArena.from_raw_pair(K0, V0, 256, kth, kth, cap_tokens=1024)
+
+    ka, va = fresh()
+    for a in (ka, va):   # room for one worst-case append behind the 256 tokens in use (what append_window_pair secures on the host)
+        if int(a.used.max()) + 256 * 128 > a.nz_cap:
+            a._rehouse(a.cap_tokens, int(a.used.max()) + 256 * 128 + 1024)
+    kw = torch.zeros((B, H, 352, 128), dtype=torch.float16, device=DEV)
+    vw = torch.zeros_like(kw)
+    scratch = torch.empty(int(L.mustafar_compress_scratch_bytes(B * H, 256)), dtype=torch.uint8, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    k_tot = torch.zeros(B * H, dtype=torch.int64, device=DEV)
+    v_tot = torch.zeros_like(k_tot)
+
+    def call(stream):
+        _lib.check(L.mustafar_cache_append_kv(stream, kw.data_ptr(), vw.data_ptr(), 352 * 128, B * H, 256, 128, kth, kth, ka.view_ptr(), va.view_ptr(),
+                                              256, k_tot.data_ptr(), v_tot.data_ptr(), ka.nz_cap, va.nz_cap, flag.data_ptr(), scratch.data_ptr()), "append_kv")
+        _lib.check(L.mustafar_window_drop_front(stream, kw.data_ptr(), vw.data_ptr(), 352 * 128, B * H, 288, 256), "drop_front")
+
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        call(torch.cuda.current_stream().cuda_stream)
+    for seed in (81, 82):
+        wk, wv = _raw(B, H, 288, seed, special=(seed == 82)), _raw(B, H, 288, seed + 10)
+        kw[:, :, :288] = wk
+        vw[:, :, :288] = wv
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(flag) == 0
+        assert torch.equal(kw[:, :, :32], wk[:, :, 256:288]) and torch.equal(vw[:, :, :32], wv[:, :, 256:288])
+        ea, eb = fresh()
+        CompressedArena.append_window_pair(ea, eb, wk.contiguous(), wv.contiguous(), 256, kth, kth)
+        for got, want, tot in ((ka, ea, k_tot), (va, eb, v_tot)):
+            t = 512 * 2
+            assert torch.equal(got.bmp[:, :t], want.bmp[:, :t]) and torch.equal(got.idx[:, :t + 1], want.idx[:, :t + 1])
+            assert torch.equal(tot.cpu(), want.used.cpu() if torch.is_tensor(want.used) else torch.as_tensor(want.used))
+            for h in range(B * H):
+                n = int(tot[h])
+                assert torch.equal(got.nz[h, :n].view(torch.int16), want.nz[h, :n].view(torch.int16))
+
+
+def test_one_pass_and_two_pass_compression_write_the_same_bytes():
+    """MUSTAFAR_COMPRESS=twopass (pass 1 + scan + pass 2, read once per process) in a child process against the default
+    one-pass kernel here: same raw rows -> identical bitmaps, offsets and streams."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from mustafar_amd import compression
+    from mustafar_amd.cache import CompressedArena
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tests.test_gpu_cache import _raw
+from mustafar_amd import compression
+from mustafar_amd.cache import CompressedArena
+K, V = _raw(2, 3, 600, 91, special=True), _raw(2, 3, 600, 92)
+ka, va = CompressedArena.from_raw_pair(K, V, 512, 89, 102)
+torch.save([ [x.cpu() for x in a.to_reference()[:2]] + [torch.cat(a.to_reference()[2]).cpu()] for a in (ka, va)], sys.argv[1])
+''' % root
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "twopass.pt")
+        env = dict(os.environ, MUSTAFAR_COMPRESS="twopass")
+        subprocess.check_call([sys.executable, "-c", code, out], env=env, cwd=root)
+        want = torch.load(out)
+    K, V = _raw(2, 3, 600, 91, special=True), _raw(2, 3, 600, 92)
+    ka, va = CompressedArena.from_raw_pair(K, V, 512, 89, 102)
+    for a, w in zip((ka, va), want):
+        r = a.to_reference()
+        assert torch.equal(r[0].cpu(), w[0]) and torch.equal(r[1].cpu(), w[1])
+        assert torch.equal(torch.cat(r[2]).cpu().view(torch.int16), w[2].view(torch.int16))
