@@ -1345,11 +1345,32 @@ __global__ __launch_bounds__(256) void value_finish_kernel(
 // and one ramp / tail less, and the value phase of a block starts behind its own key phase instead of behind ALL key
 // blocks.  Numerics: the probabilities are normalised in fp32 at the very end instead of being rounded to fp16 after
 // normalisation (:304); e carries the same 11 bits as the hook's fp16 probabilities.
+// Wave-wide maximum / sum, the same value in every lane, by DPP: two quad permutes, two rotations inside the rows of 16,
+// then the last lane of a row handed to the next row(s) (row_bcast:15 / :31) -- six VALU instructions whose operand comes
+// through the data-parallel path, and one v_readlane of lane 63.  (__shfl_xor compiles to ds_bpermute_b32 here: six LDS round
+// trips in a dependent chain per reduction, eight reductions per 64-token block in the softmax step.)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    // (written out: the compiler folds the DPP operand into v_add_f32 but emits v_mov_b32_dpp + v_max_f32 for the maximum)
+    asm("s_nop 1\n\t"   // (a DPP operand written by the previous VALU instruction needs two wait states)
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"       // every lane of a row holds the row's maximum
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"    // into rows 1 and 3
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"          // into rows 2 and 3: lane 63 holds the wave's
+        : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // A wave-uniform float kept in a scalar register (a running maximum, a rescale factor): VGPRs are what limits the
 // one-pass kernel's occupancy, and a spilled SGPR costs a lane of one shared VGPR.
@@ -1359,9 +1380,13 @@ __device__ __forceinline__ float uniform_f(float v)
 }
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f<0xB1>(0.f, v);
+    v += dpp_f<0x4E>(0.f, v);
+    v += dpp_f<0x124>(0.f, v);
+    v += dpp_f<0x128>(0.f, v);
+    v += dpp_f<0x142, 0xa>(0.f, v);
+    v += dpp_f<0x143, 0xc>(0.f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 constexpr int kOneWinChunk = 64;   // window tokens per window workgroup of the one-pass launch (one slab each)
