@@ -2078,7 +2078,19 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             const int want = (onepass_target_wgs(pair) + gy - 1) / gy;
             tb_per_wg = (ntb + want - 1) / want;
         } else {
-            tb_per_wg = 8;   // matrix-pipe form: two whole blocks per wave at every size (sweeps at c3 / c4 / c5: 1024 / 2048-4096 / 4096 workgroups)
+            // matrix-pipe form: two whole blocks per wave, or one where that fills the last round of waves much better (the chip
+            // holds 6 of these waves per SIMD: c4 with two blocks per wave runs 1.33 rounds, with one 2.65: 67 -> 63 us; c3 and c5
+            // stay at two: 0.65 and 2.67 rounds)
+            static const int slots = [] {
+                int dev = 0, cus = 256;
+                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                return (cus > 0 ? cus : 256) * 4 * 6;
+            }();
+            auto fill = [&](int tb) {
+                const double rounds = (double)gy * ((ntb + tb - 1) / tb) * kWaves / slots;
+                return rounds / ceil(rounds);
+            };
+            tb_per_wg = fill(4) > fill(8) + 0.1 ? 4 : 8;
         }
         tb_per_wg = (tb_per_wg + round - 1) / round * round;
         const int S1 = (ntb + tb_per_wg - 1) / tb_per_wg;
