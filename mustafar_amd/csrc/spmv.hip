@@ -211,25 +211,27 @@ struct Gathered {
 };
 
 #define MUSTAFAR_GATHER(j)                                                  \
-    "s_lshl2_add_u32 %[o" #j "], %[o" #j "], %[adj]\n\t"                     \
+    "s_lshl2_add_u32 %[u" #j "], %[o" #j "], %[adj]\n\t"                     \
     "v_mbcnt_lo_u32_b32 %[t" #j "], %[l" #j "], 0\n\t"                        \
     "v_mbcnt_hi_u32_b32 %[t" #j "], %[h" #j "], %[t" #j "]\n\t"               \
-    "v_lshl_add_u32 %[t" #j "], %[t" #j "], 1, %[o" #j "]\n\t"                \
+    "v_lshl_add_u32 %[t" #j "], %[t" #j "], 1, %[u" #j "]\n\t"                \
     "ds_read_u16 %[t" #j "], %[t" #j "]\n\t"
-#define MUSTAFAR_GOPS(j) [l##j] "s"((uint32_t)g.m[j]), [h##j] "s"((uint32_t)(g.m[j] >> 32))
+#define MUSTAFAR_GOPS(j) [l##j] "s"((uint32_t)g.m[j]), [h##j] "s"((uint32_t)(g.m[j] >> 32)), [o##j] "s"(m.ix[j])
 
 // Gather the 8 tiles of a step from the wave's LDS window (no wait).
 //   adj = (LDS byte address of the window) - 4 * (stream offset of its first byte)  ->  tile offset = 4*idx + adj
+// (The tile offsets land in scalar registers of their own: formed in place, the offsets -- elements of the 8-register
+// tuple the scalar load wrote -- were first copied out one s_mov_b32 each, 0.9 scalar instructions per tile.)
 __device__ __forceinline__ void gather8(const MetaB& m, uint32_t adj, Gathered& g)
 {
 #pragma unroll
     for (int j = 0; j < 8; j++) g.m[j] = __builtin_bitreverse64(m.bm[2 * j] | ((uint64_t)m.bm[2 * j + 1] << 32));
-    uint32_t o0 = m.ix[0], o1 = m.ix[1], o2 = m.ix[2], o3 = m.ix[3], o4 = m.ix[4], o5 = m.ix[5], o6 = m.ix[6], o7 = m.ix[7];
+    uint32_t u0, u1, u2, u3, u4, u5, u6, u7;
     asm volatile(MUSTAFAR_GATHER(0) MUSTAFAR_GATHER(1) MUSTAFAR_GATHER(2) MUSTAFAR_GATHER(3)
                  MUSTAFAR_GATHER(4) MUSTAFAR_GATHER(5) MUSTAFAR_GATHER(6) MUSTAFAR_GATHER(7)
                  : [t0] "=&v"(g.t[0]), [t1] "=&v"(g.t[1]), [t2] "=&v"(g.t[2]), [t3] "=&v"(g.t[3]), [t4] "=&v"(g.t[4]),
-                   [t5] "=&v"(g.t[5]), [t6] "=&v"(g.t[6]), [t7] "=&v"(g.t[7]), [o0] "+s"(o0), [o1] "+s"(o1), [o2] "+s"(o2),
-                   [o3] "+s"(o3), [o4] "+s"(o4), [o5] "+s"(o5), [o6] "+s"(o6), [o7] "+s"(o7)
+                   [t5] "=&v"(g.t[5]), [t6] "=&v"(g.t[6]), [t7] "=&v"(g.t[7]), [u0] "=&s"(u0), [u1] "=&s"(u1), [u2] "=&s"(u2),
+                   [u3] "=&s"(u3), [u4] "=&s"(u4), [u5] "=&s"(u5), [u6] "=&s"(u6), [u7] "=&s"(u7)
                  : MUSTAFAR_GOPS(0), MUSTAFAR_GOPS(1), MUSTAFAR_GOPS(2), MUSTAFAR_GOPS(3), MUSTAFAR_GOPS(4), MUSTAFAR_GOPS(5),
                    MUSTAFAR_GOPS(6), MUSTAFAR_GOPS(7), [adj] "s"(adj)
                  : "scc");
