@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64, 2) void compress_block_kernel(Side s0, Side s1,
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const uint32_t base = (rows.tile0 ? (uint32_t)head_acc[0] : 0u) + sum;   // (append: entry tile0 holds the head's length so far, model :352-360)
     if (__ballot(failed)) {
-        if (lane == 0) atomicOr(overflow, 2);
+        if (lane == 0 && overflow) atomicOr(overflow, 2);
         return;
     }
     // ---- metadata of the block's 128 tiles: bitmaps, offsets (exclusive prefix over the whole head, compression.py:294-298)

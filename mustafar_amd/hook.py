@@ -239,15 +239,15 @@ class MustafarAttention:
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
         pool = self.__dict__.setdefault("_fused_scratch", {})
         sc, ws = pool.get(key, (None, None))
-        # Grown with headroom (two more 256-token triggers) and never freed while this object lives: a captured graph of an
-        # earlier call keeps the old addresses (bench.py captures the graph of the NEXT cache length while the current one is
-        # still being replayed).
+        # Grown geometrically (+ two 256-token triggers of headroom) and never freed while this object lives: a captured graph
+        # of an earlier call keeps the old addresses (bench.py records the graph of the NEXT cache length while the current one
+        # is still being replayed).  Geometric growth keeps the retired buffers a small multiple of the live one.
         if sc is None or sc.numel() < BH * ld:
             self.__dict__.setdefault("_retired_scratch", []).append(sc)
-            sc = torch.empty(BH * (ld + 512), dtype=torch.float16, device=device)
+            sc = torch.empty(max(BH * (ld + 512), (sc.numel() * 5) // 4 if sc is not None else 0), dtype=torch.float16, device=device)
         if ws is None or ws.numel() < ws_bytes:
             self.__dict__.setdefault("_retired_scratch", []).append(ws)
-            ws = torch.empty(max(ws_bytes + ws_bytes // 8, 1 << 20), dtype=torch.uint8, device=device)
+            ws = torch.empty(max(ws_bytes + ws_bytes // 8, (ws.numel() * 5) // 4 if ws is not None else 0, 1 << 20), dtype=torch.uint8, device=device)
         pool[key] = (sc, ws)
         return sc, ws
 
