@@ -8,8 +8,8 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference-api --no-other-configs --no-trigger-leg > $O/bench_c3_under_rocprof.json 2>/dev/null )
 cp $(ls $O/rocprof_bench/*/*kernel_stats.csv | head -1) $O/bench_c3_kernel_stats.csv && echo "rocprof done"
 tools/prof_pmc.sh ${TAG}_valu c5 > /dev/null 2>&1; cp gpurun_out/pmc_${TAG}_valu.txt $O/pmc_sq_c5_valu.txt
-PROF_FUSED=1 tools/prof_pmc.sh ${TAG}_valu_c3 c3 > /dev/null 2>&1; cp gpurun_out/pmc_${TAG}_valu_c3.txt $O/pmc_sq_c3_valu_with_onepass.txt
-PROF_FUSED=1 MUSTAFAR_FMA_ENGINE=mfma tools/prof_pmc.sh ${TAG}_mfma_c3 c3 > /dev/null 2>&1; cp gpurun_out/pmc_${TAG}_mfma_c3.txt $O/pmc_sq_c3_mfma_with_onepass.txt
+PROF_FUSED=1 tools/prof_pmc.sh ${TAG}_valu_c3 c3 > /dev/null 2>&1; for p in A B C; do python3 tools/pmc_summary.py gpurun_out/pmc_${TAG}_valu_c3_$p --match onepass_kernel; done > $O/pmc_sq_c3_valu_onepass.txt
+PROF_FUSED=1 MUSTAFAR_FMA_ENGINE=mfma tools/prof_pmc.sh ${TAG}_mfma_c3 c3 > /dev/null 2>&1; for p in A B C; do python3 tools/pmc_summary.py gpurun_out/pmc_${TAG}_mfma_c3_$p --match onepass_kernel; done > $O/pmc_sq_c3_mfma_onepass.txt
 MUSTAFAR_FMA_ENGINE=mfma tools/prof_pmc.sh ${TAG}_mfma c5 > /dev/null 2>&1; cp gpurun_out/pmc_${TAG}_mfma.txt $O/pmc_sq_c5_mfma.txt; echo "pmc done"
 python3 tools/mem_spd.py --api fused reference > $O/mem_spd.txt 2>&1; python3 tools/mem_spd.py --api fused --graph >> $O/mem_spd.txt 2>&1; echo "mem_spd done"
 python3 tools/bench_compress.py c3 c4 2>&1 | grep cfg > $O/compress.txt; python3 tools/bench_append.py 2>&1 | grep cfg > $O/append.txt
