@@ -292,3 +292,19 @@ torch.save([ [x.cpu() for x in a.to_reference()[:2]] + [torch.cat(a.to_reference
         r = a.to_reference()
         assert torch.equal(r[0].cpu(), w[0]) and torch.equal(r[1].cpu(), w[1])
         assert torch.equal(torch.cat(r[2]).cpu().view(torch.int16), w[2].view(torch.int16))
+
+
+@pytest.mark.parametrize("B,H,t", [(1, 1, 64), (1, 3, 192), (2, 1, 1024)])
+def test_one_pass_compression_of_pruned_rows_and_small_shapes(B, H, t):
+    """kth = 0 (rows already pruned: no threshold search) through the one-pass kernel, at one block per head, an odd number of
+    heads and sixteen blocks per head (the blocks of a head find their stream positions from each other): equal to the two-call
+    conversion of the same rows."""
+    from mustafar_amd import compression
+    from mustafar_amd.cache import CompressedArena
+    X = compression.prune_magnitude(_raw(B, H, t, 97, special=(t >= 192)).reshape(B * H, t, 128), 0.7).reshape(B, H, t, 128)
+    ka, va = CompressedArena.from_raw_pair(X, X, t, 0, 0)
+    for which, arena in (("key", ka), ("value", va)):
+        want = CompressedArena.from_pruned(X.reshape(B * H, t, 128), which)
+        a, w = arena.to_reference(), want.to_reference()
+        assert torch.equal(a[0], w[0]) and torch.equal(a[1], w[1]) and torch.equal(a[3], w[3])
+        assert torch.equal(torch.cat(a[2]).view(torch.int16), torch.cat(w[2]).view(torch.int16))
