@@ -33,7 +33,7 @@ allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[cfg] = entry
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
-for f in ("spmv.hip", "compress.hip"):   # bench.py's kernel_source_tag(): a figure is only reported for the kernels it was measured on
+for f in ("spmv.hip",):   # bench.py's kernel_source_tag(): a figure is only reported for the kernels it was measured on
     h.update(open(os.path.join(ROOT, "mustafar_amd", "csrc", f), "rb").read())
 allj["kernel_source_tag"] = h.hexdigest()[:12]
 allj["_note"] = ("bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB counters; gfx950 FETCH_SIZE halves wide reads, calibrated on a "
