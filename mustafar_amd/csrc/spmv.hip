@@ -1731,6 +1731,18 @@ __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __rest
     __shared__ float sh[4];
     __shared__ float part[kD];
     const int bh = blockIdx.x, tid = threadIdx.x;
+    const int c = tid & (kD - 1), par = tid >> 7;
+    const int64_t total = (int64_t)BH * kD;
+    const float* src = ws_o + (int64_t)bh * kD + c;
+    // The first 64 slabs' outputs are requested BEFORE the weights are known: the loads fly while the maxima / sums are
+    // loaded and reduced (the kernel is two dependent memory round trips otherwise; 62-68 slabs at c3).
+    constexpr int kEarly = 32;   // per thread: slabs par, par + 2, ..., par + 62
+    float v[kEarly];
+#pragma unroll
+    for (int i = 0; i < kEarly; i++) {
+        const int k = par + 2 * i;
+        v[i] = (k < S) ? src[(int64_t)k * total] : 0.f;
+    }
     float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;   // slabs tid and tid + 256
     if (tid < S) { m0 = ws_ml[((int64_t)tid * BH + bh) * 2]; l0 = ws_ml[((int64_t)tid * BH + bh) * 2 + 1]; }
     if (tid + 256 < S) { m1 = ws_ml[((int64_t)(tid + 256) * BH + bh) * 2]; l1 = ws_ml[((int64_t)(tid + 256) * BH + bh) * 2 + 1]; }
@@ -1739,11 +1751,16 @@ __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __rest
     if (tid < S) wgt[tid] = w0;
     if (tid + 256 < S) wgt[tid + 256] = w1;
     const float denom = block_reduce<4>(w0 * l0 + w1 * l1, false, sh);   // (its barriers also publish wgt[])
-    const int c = tid & (kD - 1), par = tid >> 7;
-    const int64_t total = (int64_t)BH * kD;
-    const float* src = ws_o + (int64_t)bh * kD + c;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = par;
+#pragma unroll
+    for (int i = 0; i < kEarly; i += 4) {   // (slabs beyond S were read as zero; their weights are never read)
+        const int k = par + 2 * i;
+        if (k < S)     s0 += wgt[k] * v[i];
+        if (k + 2 < S) s1 += wgt[k + 2] * v[i + 1];
+        if (k + 4 < S) s2 += wgt[k + 4] * v[i + 2];
+        if (k + 6 < S) s3 += wgt[k + 6] * v[i + 3];
+    }
+    int k = par + 2 * kEarly;
     for (; k + 6 < S; k += 8) {
         s0 += wgt[k] * src[(int64_t)k * total];
         s1 += wgt[k + 2] * src[(int64_t)(k + 2) * total];
