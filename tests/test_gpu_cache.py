@@ -308,3 +308,34 @@ def test_one_pass_compression_of_pruned_rows_and_small_shapes(B, H, t):
         a, w = arena.to_reference(), want.to_reference()
         assert torch.equal(a[0], w[0]) and torch.equal(a[1], w[1]) and torch.equal(a[3], w[3])
         assert torch.equal(torch.cat(a[2]).view(torch.int16), torch.cat(w[2]).view(torch.int16))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_one_pass_compression_randomised_against_the_oracle(seed):
+    """Random shapes, sparsities and value distributions (quantised values: many ties at the threshold; blocks of zeros; a few
+    huge and a few subnormal entries) through prune + compress in one pass, K and V with different k, against oracle prune +
+    oracle compress bit for bit."""
+    from mustafar_amd import compression
+    from mustafar_amd.cache import CompressedArena
+    rng = np.random.default_rng(1000 + seed)
+    B, H = int(rng.integers(1, 3)), int(rng.integers(1, 5))
+    t = 64 * int(rng.integers(1, 9))
+    L = t + int(rng.integers(0, 3)) * 32
+    s_k, s_v = float(rng.choice([0.3, 0.5, 0.7, 0.8, 0.9])), float(rng.choice([0.3, 0.5, 0.7, 0.8, 0.9]))
+
+    def make():
+        x = rng.standard_normal((B, H, L, 128)).astype(np.float32)
+        mode = rng.integers(0, 4)
+        if mode == 1:
+            x = np.round(x * 2) / 2                      # heavy ties
+        elif mode == 2:
+            x[rng.random(x.shape) < 0.6] = 0.0           # already sparse: thresholds of zero, empty tiles
+        elif mode == 3:
+            x *= 10.0 ** rng.integers(-7, 4, size=(B, H, L, 1))   # rows from subnormal to large
+        x[rng.random(x.shape) < 0.01] *= -0.0
+        return torch.from_numpy(np.clip(x, -65504, 65504).astype(np.float16)).to(DEV)
+
+    K, V = make(), make()
+    ka, va = CompressedArena.from_raw_pair(K, V, t, compression.kth_from_sparsity(s_k, 128), compression.kth_from_sparsity(s_v, 128))
+    _assert_same_as_oracle(ka, _oracle_pruned(K, s_k, t), "key")
+    _assert_same_as_oracle(va, _oracle_pruned(V, s_v, t), "value")

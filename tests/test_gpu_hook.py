@@ -179,3 +179,35 @@ def test_fused_decode_with_rows_longer_than_32768():
         out, past = attn.decode(qn, kn, vn, past)
         want = _dense_reference(qn, K, V, 33024, 0.7, 0.7, hq // hkv)
         torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
+
+
+def test_fused_decode_on_two_streams_at_once():
+    """Two streams, each with its own cache and its own scratch (hook.py keeps score scratch and slab workspace per device and
+    stream): the calls are enqueued alternately without a sync in between and must give what the same calls give one after the
+    other."""
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    torch.manual_seed(5)
+    cfg = MustafarConfig(num_attention_heads=8, num_key_value_heads=2, k_sparsity=0.7, v_sparsity=0.7, residual_length=32, api="fused", arena=True)
+    attn = MustafarAttention(cfg)
+    dev = "cuda:0"
+    K = [torch.randn(2, 2, 1056, 128, device=dev).half() for _ in range(2)]
+    V = [torch.randn(2, 2, 1056, 128, device=dev).half() for _ in range(2)]
+    steps = [[tuple(torch.randn(2, h, 1, 128, device=dev).half() for h in (8, 2, 2)) for _ in range(6)] for _ in range(2)]
+
+    def run(parallel):
+        pasts = [attn.to_fused(attn.build_cache(K[i], V[i])) for i in range(2)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()] if parallel else [torch.cuda.current_stream()] * 2
+        torch.cuda.synchronize()
+        outs = [[], []]
+        for n in range(6):
+            for i in range(2):
+                with torch.cuda.stream(streams[i]):
+                    q, k, v = steps[i][n]
+                    o, pasts[i] = attn.decode(q, k, v, pasts[i])
+                    outs[i].append(o)
+        torch.cuda.synchronize()
+        return [torch.stack(o) for o in outs]
+
+    serial, parallel = run(False), run(True)
+    for a, b in zip(serial, parallel):
+        assert torch.equal(a, b)
