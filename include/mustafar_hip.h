@@ -213,6 +213,8 @@ int mustafar_get_fma_engine(void);
  */
 int mustafar_set_onepass(int mode);
 int mustafar_get_onepass(void);
+/* Tuning knobs for the measurement scripts under tools/ (launch shapes of the one-pass forms); not an operator interface. */
+int mustafar_tune(int knob, int value);
 
 /*
  * Live kernel timing inside mustafar_decode_attention (bench.py roofline leg): HIP events that receive the start and

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mustafar_get_fma_engine": (_i32, []),
     "mustafar_set_onepass": (_i32, [_i32]),
     "mustafar_get_onepass": (_i32, []),
+    "mustafar_tune": (_i32, [_i32, _i32]),
     "mustafar_profile_begin": (_i32, [_i32]),
     "mustafar_profile_end": (_i32, [_vp, _vp, _vp]),
     "mustafar_prune_magnitude": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32]),

@@ -64,9 +64,38 @@ struct WaveTrace {
 };
 #define MUSTAFAR_TRACE_BEGIN(k) const WaveTrace wave_trace_(k)
 #define MUSTAFAR_TRACE_END() wave_trace_.end()
+// One-pass launches (tools/wave_trace_onepass.py): 16 x u64 per wave -- t[0] start, t[1] first key chunk staged, t[2] key phase
+// done, t[3] softmax step done, t[4] first value chunk staged, t[5] value phase done (all of the wave's FIRST block), t[6] end;
+// [8] HW_ID / XCC_ID, [9] grid position, [10] valid.  Slot = the wave's linear grid position.
+struct PhaseTrace {
+    unsigned long long t[7];
+    __device__ PhaseTrace() { t[0] = __builtin_amdgcn_s_memrealtime(); for (int i = 1; i < 7; i++) t[i] = 0; }
+    __device__ void stamp(int i) { if (t[i] == 0) t[i] = __builtin_amdgcn_s_memrealtime(); }
+    __device__ void end(unsigned int kernel)
+    {
+        if (g_trace_buf == nullptr || (threadIdx.x & 63) != 0) return;
+        t[6] = __builtin_amdgcn_s_memrealtime();
+        const unsigned int w = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (w >= g_trace_cap / 4) return;
+        const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        unsigned long long* r = g_trace_buf + 16ull * w;
+        for (int i = 0; i < 7; i++) r[i] = t[i];
+        r[8] = ((unsigned long long)xcc << 32) | hw;
+        r[9] = ((unsigned long long)kernel << 56) | ((unsigned long long)(threadIdx.x >> 6) << 48) | ((unsigned long long)blockIdx.y << 24) | blockIdx.x;
+        r[10] = 1;
+    }
+};
+#define MUSTAFAR_PTRACE_BEGIN() PhaseTrace phase_trace_
+#define MUSTAFAR_PTRACE_STAMP(i) phase_trace_.stamp(i)
+#define MUSTAFAR_PTRACE_END(k) phase_trace_.end(k)
+#define MUSTAFAR_PTRACE_ARG , phase_trace_
 #else
 #define MUSTAFAR_TRACE_BEGIN(k)
 #define MUSTAFAR_TRACE_END()
+#define MUSTAFAR_PTRACE_BEGIN()
+#define MUSTAFAR_PTRACE_STAMP(i)
+#define MUSTAFAR_PTRACE_END(k)
+#define MUSTAFAR_PTRACE_ARG
 #endif
 
 constexpr int kWaves      = 4;                    // waves per workgroup (key kernel; the value kernel defaults to kValueWaves = 8)
@@ -107,12 +136,18 @@ __device__ __forceinline__ Stage stage_issue(const unsigned char* __restrict__ s
     const int off = lane * 16;
     Stage s;
     u32x4 t;
+    // Cache policy of the stream loads: non-temporal (aux bit 1 = nt on gfx940+).  Every stream byte is read once per launch; with
+    // the default policy that traffic pushed the metadata lines out of L2 between their vector prefetch and the scalar loads
+    // that use them (c3 one-pass, pair grain: 52.3 -> 48.1 us with nt alone).  MUSTAFAR_STREAM_AUX: experiment knob.
+#ifndef MUSTAFAR_STREAM_AUX
+#define MUSTAFAR_STREAM_AUX 2
+#endif
     // (skipping the 1-KiB pieces that lie wholly beyond the chunk's data -- a chunk is ~1.5 KiB at 70 % sparsity -- was
     // measured in round 2: the scalar branches cost the VALU engine 2-3 %, the matrix-pipe engine nothing either way)
-    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);        s.r0 = {t.x, t.y, t.z, t.w};
-    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024, 0, 0); s.r1 = {t.x, t.y, t.z, t.w};
-    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048, 0, 0); s.r2 = {t.x, t.y, t.z, t.w};
-    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072, 0, 0); s.r3 = {t.x, t.y, t.z, t.w};
+    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, MUSTAFAR_STREAM_AUX);        s.r0 = {t.x, t.y, t.z, t.w};
+    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024, 0, MUSTAFAR_STREAM_AUX); s.r1 = {t.x, t.y, t.z, t.w};
+    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048, 0, MUSTAFAR_STREAM_AUX); s.r2 = {t.x, t.y, t.z, t.w};
+    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072, 0, MUSTAFAR_STREAM_AUX); s.r3 = {t.x, t.y, t.z, t.w};
     return s;
 }
 
@@ -181,7 +216,11 @@ __device__ __forceinline__ void metab_issue(MetaB& m, const uint64_t* __restrict
                  : "=&s"(m.bm), "=&s"(m.ix)
                  : "s"(bmp), "s"(idx), "i"(S * 64), "i"(S * 32));
 }
+#ifdef MUSTAFAR_PROBE_NOMETAWAIT   // timing-only build: the next step does not wait for its metadata; results wrong (LDS reads out of range return 0)
+__device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_nop 0" : "+s"(m.bm), "+s"(m.ix)); }
+#else
 __device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix)); }
+#endif
 // Ordering point without an instruction: legal right after a wait that already drained the counter.
 __device__ __forceinline__ void metab_ready(MetaB& m) { asm volatile("" : "+s"(m.bm), "+s"(m.ix)); }
 
@@ -210,12 +249,17 @@ struct Gathered {
     uint32_t t[8];   // gathered halfs (VGPRs; meaningful only in lanes whose bit is set, and only after gather_wait)
 };
 
+#ifdef MUSTAFAR_PROBE_NOGATHER   // timing-only build: no LDS gather (the address stands in for the value); results wrong
+#define MUSTAFAR_GATHER_LD(j) "v_mov_b32 %[t" #j "], %[t" #j "]\n\t"
+#else
+#define MUSTAFAR_GATHER_LD(j) "ds_read_u16 %[t" #j "], %[t" #j "]\n\t"
+#endif
 #define MUSTAFAR_GATHER(j)                                                  \
     "s_lshl2_add_u32 %[u" #j "], %[o" #j "], %[adj]\n\t"                     \
     "v_mbcnt_lo_u32_b32 %[t" #j "], %[l" #j "], 0\n\t"                        \
     "v_mbcnt_hi_u32_b32 %[t" #j "], %[h" #j "], %[t" #j "]\n\t"               \
     "v_lshl_add_u32 %[t" #j "], %[t" #j "], 1, %[u" #j "]\n\t"                \
-    "ds_read_u16 %[t" #j "], %[t" #j "]\n\t"
+    MUSTAFAR_GATHER_LD(j)
 #define MUSTAFAR_GOPS(j) [l##j] "s"((uint32_t)g.m[j]), [h##j] "s"((uint32_t)(g.m[j] >> 32)), [o##j] "s"(m.ix[j])
 
 // Gather the 8 tiles of a step from the wave's LDS window (no wait).
@@ -238,11 +282,16 @@ __device__ __forceinline__ void gather8(const MetaB& m, uint32_t adj, Gathered& 
 }
 
 // Drains the counter: the gathers AND the coefficient loads issued before them.
+#ifdef MUSTAFAR_PROBE_NOLDSWAIT   // timing-only build: the FMAs do not wait for the gathers (nor the coefficients); results wrong
+#define MUSTAFAR_GWAIT "s_nop 0"
+#else
+#define MUSTAFAR_GWAIT "s_waitcnt lgkmcnt(0)"
+#endif
 template <int G>
 __device__ __forceinline__ void gather_wait(Gathered& g, u32x4 (&c)[G])
 {
     if constexpr (G == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)"
+        asm volatile(MUSTAFAR_GWAIT
                      : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]), "+v"(g.t[7]),
                        "+s"(c[0]), "+s"(c[1]), "+s"(c[2]), "+s"(c[3]));
     else if constexpr (G == 2)
@@ -1409,8 +1458,21 @@ struct OneArgs {   // operands of the one-pass launch beyond the two caches (by 
 };
 
 // Window workgroup: 64 window tokens of one head batch -> scores, softmax partial, p.V partial -> slab (S + chunk).
+// (the OneArgs fields arrive through a by-value copy of the few that are needed: a reference to the kernel argument pins the
+// whole struct to a stack slot, and a kernel with a private segment -- even one it never touches -- is launched with scratch)
+struct WinOneArgs {
+    const h16* q; float* ws_o; float* ws_ml; h16* k_win; h16* v_win; const h16* k_new; const h16* v_new; const h16* mask_ptr;
+    int64_t mask_stride;
+    int mask_heads, T, groups, BH, w_len, w_cap, nchunks;
+    float inv_sqrt_d;
+};
+__device__ __forceinline__ WinOneArgs win_args(const OneArgs& a)
+{
+    return WinOneArgs{a.q, a.ws_o, a.ws_ml, a.k_win, a.v_win, a.k_new, a.v_new, a.mask.ptr, a.mask.stride, a.mask.heads, a.T, a.groups, a.BH,
+                      window_len(a.w_extra, a.w_len, a.w_cap), a.w_cap, a.nchunks, a.inv_sqrt_d};
+}
 template <int G>
-__device__ __forceinline__ void onepass_window_wg(unsigned char* smem, const OneArgs& a, int task, int S)
+__device__ __forceinline__ void onepass_window_wg(unsigned char* smem, const WinOneArgs a, int task, int S)
 {
     constexpr int kRedLd = kD + 4;
     float* xs = reinterpret_cast<float*>(smem);                    // [G][64] scores, then e
@@ -1421,7 +1483,7 @@ __device__ __forceinline__ void onepass_window_wg(unsigned char* smem, const One
     const int hb_per_kv = a.groups / G;
     const int hb = task / a.nchunks, chunk = task % a.nchunks;
     const int kvh = hb / hb_per_kv, bh0 = kvh * a.groups + (hb % hb_per_kv) * G;
-    const int w_len = window_len(a.w_extra, a.w_len, a.w_cap);
+    const int w_len = a.w_len;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w0 = chunk * kOneWinChunk;
     float* slab_o = a.ws_o + ((int64_t)(S + chunk) * a.BH + bh0) * kD;
@@ -1449,7 +1511,7 @@ __device__ __forceinline__ void onepass_window_wg(unsigned char* smem, const One
         for (int c = 0; c < 4; c++) reinterpret_cast<uint4*>(kwin + (int64_t)w * kD + part * 32)[c] = kv[c].u;
     }
     __syncthreads();
-    const h16* mrow = a.mask.ptr ? a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride + a.T : nullptr;
+    const h16* mrow = a.mask_ptr ? a.mask_ptr + (int64_t)(bh0 / a.mask_heads) * a.mask_stride + a.T : nullptr;
 #pragma unroll
     for (int h = 0; h < G; h++) {
         float acc = 0.f;
@@ -1545,12 +1607,14 @@ __global__ __launch_bounds__(kThreads, MF ? 5 : 1) void decode_onepass_kernel(  
     constexpr int kTabBytes = (MF && G == 4) ? 4 * kKeyTabStride + kWaves * 4 * kValTabStride : 0;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
     static_assert(kWaves * kStageBytes >= (kWaves * 2 * 4 * 64 + 2 * kWaves * 4) * 4, "combine buffers must fit in the stage area");
+    MUSTAFAR_PTRACE_BEGIN();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = gridDim.x;
     if ((int)blockIdx.y < a.win_rows) {   // dense window
         const int task = blockIdx.y * gridDim.x + blockIdx.x;
-        if (task < (int)(gridDim.y - a.win_rows) * a.nchunks) onepass_window_wg<G>(smem, a, task, S);
+        if (task < (int)(gridDim.y - a.win_rows) * a.nchunks) onepass_window_wg<G>(smem, win_args(a), task, S);
+        MUSTAFAR_PTRACE_END(5);
         return;
     }
     const int by = blockIdx.y - a.win_rows;
@@ -1620,10 +1684,13 @@ __global__ __launch_bounds__(kThreads, MF ? 5 : 1) void decode_onepass_kernel(  
             for (int h = 0; h < G; h++) s[h] = 0.f;
             key_tokblk<G, MF, 0, 4>(smem, wave * kStageBytes, kb + (int64_t)tb * kTilesPerTb, ki + (int64_t)tb * kTilesPerTb, kn, qw, kD / 2,
                                     lane, s, ctab_lane);
+            MUSTAFAR_PTRACE_STAMP(2);
             softmax_step(tb, s, alpha);
+            MUSTAFAR_PTRACE_STAMP(3);
 #pragma unroll
             for (int h = 0; h < G; h++) { acc0[h] *= alpha[h]; acc1[h] *= alpha[h]; }
             value_tokblks<G, MF, 0, 4, 1, MF && G == 4>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
+            MUSTAFAR_PTRACE_STAMP(5);
         }
     } else {
         const int pair = wave >> 1, odd = wave & 1;
@@ -1645,6 +1712,7 @@ __global__ __launch_bounds__(kThreads, MF ? 5 : 1) void decode_onepass_kernel(  
                     for (int h = 0; h < G; h++) xch[h * 64 + lane] = s[h];
                 }
             }
+            MUSTAFAR_PTRACE_STAMP(2);
             __syncthreads();
             if (active && !odd) {
 #pragma unroll
@@ -1658,6 +1726,7 @@ __global__ __launch_bounds__(kThreads, MF ? 5 : 1) void decode_onepass_kernel(  
                 }
             }
             __syncthreads();
+            MUSTAFAR_PTRACE_STAMP(3);
             if (active) {
                 if (odd) {
 #pragma unroll
@@ -1669,6 +1738,7 @@ __global__ __launch_bounds__(kThreads, MF ? 5 : 1) void decode_onepass_kernel(  
                 if (odd) value_tokblks<G, MF, 2, 2, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
                 else     value_tokblks<G, MF, 0, 2, 1>(smem, wave * kStageBytes, vb, vi, vn, pw, (uint32_t)a.ld / 2u, tb, tb + 1, lane, acc0, acc1, ptab);
             }
+            MUSTAFAR_PTRACE_STAMP(5);
         }
         if (odd) {   // maximum and sum live in the even wave; the odd wave contributes its output half only
 #pragma unroll
@@ -1719,6 +1789,7 @@ __global__ __launch_bounds__(kThreads, MF ? 5 : 1) void decode_onepass_kernel(  
         slab_ml[0] = M;
         slab_ml[1] = L;
     }
+    MUSTAFAR_PTRACE_END(MF ? 6 : 4);
 }
 
 // out[bh, c] = fp16( sum_s w_s * o_s[c] / sum_s w_s * l_s ),  w_s = exp(m_s - max_s m_s)   (the softmax of :304 and the
@@ -1774,6 +1845,519 @@ __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __rest
     if (!par) out[(int64_t)bh * kD + c] = (h16)((s + part[c]) / denom);
 }
 
+// ------------------------------------------------------------------------------------------------ one-pass decode, lean form (G = 4)
+// Same algorithm and slabs as decode_onepass_kernel, rebuilt around what the round-2 counters showed: at c3 a workgroup of the
+// pair form runs its block loop ONCE, and 2.3 of its 11.3 vector instructions per tile were the start-up and merge code around
+// that single iteration (sixteen hoisted coefficient pointers and a dozen chunk pointers spilled to VGPR lanes, the pair
+// exchange, two barriers).  Here
+//   * a wave owns whole 64-token blocks (no exchange, no barrier before the final merge);
+//   * every address inside a block is ONE base pointer + an immediate: the chunk's bitmaps / offsets (tile offset TOFF), the
+//     coefficients of the four heads (rows HS bytes apart: the q rows are contiguous, and the e segments of a block are laid out
+//     [head][64 tokens] in the score scratch, which is this kernel's to arrange), so nothing per chunk or per head is
+//     computed, hoisted or spilled;
+//   * FMA phase (ENG): 0 = four v_fma_mix_f32 per tile under EXEC = bitmap (as chunk32), or
+//     2 = v_dot2_f32_f16 on PAIRS of tiles: the gathers run under EXEC = bitmap into zeroed registers (even tile -> low half,
+//     odd tile -> high half through ds_read_u16_d16_hi, packed by one full-rate v_or_b32), then ONE v_dot2 per head and pair:
+//     per tile 3 + 2 half-rate and 1.5 full-rate vector instructions instead of 3 + 4.  v_dot2_f32_f16 flushes fp16
+//     SUBNORMAL inputs (tools/ubench/dot2_numerics.hip); the softmax weights therefore travel scaled by 2^15 (e in
+//     (2^-29, 1] stays normal; the factor cancels between the output and the denominator and is removed exactly when the slab
+//     is written), and a non-zero K / V / q element below 2^-14 counts as zero -- an absolute error below 6.1e-5 x |coefficient|
+//     per such element, far inside the fp16 rounding of the scores and outputs themselves.
+template <int TOFF>
+__device__ __forceinline__ void metab_issue_at(MetaB& m, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx)
+{
+#ifdef MUSTAFAR_PROBE_HOTMETA
+    asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx8 %1, %3, %5"
+                 : "=&s"(m.bm), "=&s"(m.ix)
+                 : "s"(g_hot_bmp), "s"(g_hot_idx), "i"((TOFF % 32) * 8), "i"((TOFF % 32) * 4));
+#else
+    asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx8 %1, %3, %5"
+                 : "=&s"(m.bm), "=&s"(m.ix)
+                 : "s"(bmp), "s"(idx), "i"(TOFF * 8), "i"(TOFF * 4));
+#endif
+}
+// coefficients of one step for the four heads: 16 bytes each at base + OFF + h * HS
+template <int OFF, int HS>
+__device__ __forceinline__ void coef4_issue_at(u32x4 (&c)[4], const void* __restrict__ base)
+{
+    asm volatile("s_load_dwordx4 %0, %4, %5\n\ts_load_dwordx4 %1, %4, %6\n\t"
+                 "s_load_dwordx4 %2, %4, %7\n\ts_load_dwordx4 %3, %4, %8"
+                 : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3])
+                 : "s"(base), "i"(OFF), "i"(OFF + HS), "i"(OFF + 2 * HS), "i"(OFF + 3 * HS));
+}
+
+struct Gathered2 {
+    uint32_t t[8];   // gathered halfs, EXACT zero where the tile has no element in the lane: even tiles bits 15:0, odd tiles bits 31:16
+};
+// rank and LDS address of tile j in address register k (four address registers and four scalar temporaries serve eight tiles)
+#define MUSTAFAR_D2_RANK(j, k)                                              \
+    "s_lshl2_add_u32 %[u" #k "], %[o" #j "], %[adj]\n\t"                     \
+    "v_mbcnt_lo_u32_b32 %[x" #k "], %[l" #j "], 0\n\t"                        \
+    "v_mbcnt_hi_u32_b32 %[x" #k "], %[h" #j "], %[x" #k "]\n\t"               \
+    "v_lshl_add_u32 %[x" #k "], %[x" #k "], 1, %[u" #k "]\n\t"                \
+    "v_mov_b32 %[t" #j "], 0\n\t"
+#define MUSTAFAR_D2_LOAD(j, k) "s_mov_b64 exec, %[m" #j "]\n\tds_read_u16 %[t" #j "], %[x" #k "]\n\t"
+#define MUSTAFAR_D2_LOAD_HI(j, k) "s_mov_b64 exec, %[m" #j "]\n\tds_read_u16_d16_hi %[t" #j "], %[x" #k "]\n\t"
+// (EXEC contract as fma8 / gather8_clean: full wave at entry, restored before the statement ends)
+__device__ __forceinline__ void gather8_d2(const MetaB& m, uint32_t adj, Gathered2& g)
+{
+    const uint64_t m0 = __builtin_bitreverse64(m.bm[0] | ((uint64_t)m.bm[1] << 32));
+    const uint64_t m1 = __builtin_bitreverse64(m.bm[2] | ((uint64_t)m.bm[3] << 32));
+    const uint64_t m2 = __builtin_bitreverse64(m.bm[4] | ((uint64_t)m.bm[5] << 32));
+    const uint64_t m3 = __builtin_bitreverse64(m.bm[6] | ((uint64_t)m.bm[7] << 32));
+    const uint64_t m4 = __builtin_bitreverse64(m.bm[8] | ((uint64_t)m.bm[9] << 32));
+    const uint64_t m5 = __builtin_bitreverse64(m.bm[10] | ((uint64_t)m.bm[11] << 32));
+    const uint64_t m6 = __builtin_bitreverse64(m.bm[12] | ((uint64_t)m.bm[13] << 32));
+    const uint64_t m7 = __builtin_bitreverse64(m.bm[14] | ((uint64_t)m.bm[15] << 32));
+    uint32_t x0, x1, x2, x3, u0, u1, u2, u3;
+    asm volatile(MUSTAFAR_D2_RANK(0, 0) MUSTAFAR_D2_RANK(1, 1) MUSTAFAR_D2_RANK(2, 2) MUSTAFAR_D2_RANK(3, 3)
+                 MUSTAFAR_D2_LOAD(0, 0) MUSTAFAR_D2_LOAD_HI(1, 1) MUSTAFAR_D2_LOAD(2, 2) MUSTAFAR_D2_LOAD_HI(3, 3)
+                 "s_mov_b64 exec, -1\n\t"
+                 MUSTAFAR_D2_RANK(4, 0) MUSTAFAR_D2_RANK(5, 1) MUSTAFAR_D2_RANK(6, 2) MUSTAFAR_D2_RANK(7, 3)
+                 MUSTAFAR_D2_LOAD(4, 0) MUSTAFAR_D2_LOAD_HI(5, 1) MUSTAFAR_D2_LOAD(6, 2) MUSTAFAR_D2_LOAD_HI(7, 3)
+                 "s_mov_b64 exec, -1"
+                 : [t0] "=&v"(g.t[0]), [t1] "=&v"(g.t[1]), [t2] "=&v"(g.t[2]), [t3] "=&v"(g.t[3]), [t4] "=&v"(g.t[4]),
+                   [t5] "=&v"(g.t[5]), [t6] "=&v"(g.t[6]), [t7] "=&v"(g.t[7]), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2),
+                   [x3] "=&v"(x3), [u0] "=&s"(u0), [u1] "=&s"(u1), [u2] "=&s"(u2), [u3] "=&s"(u3)
+                 : MUSTAFAR_MOPS(0), MUSTAFAR_MOPS(1), MUSTAFAR_MOPS(2), MUSTAFAR_MOPS(3), MUSTAFAR_MOPS(4), MUSTAFAR_MOPS(5),
+                   MUSTAFAR_MOPS(6), MUSTAFAR_MOPS(7), [o0] "s"(m.ix[0]), [o1] "s"(m.ix[1]), [o2] "s"(m.ix[2]), [o3] "s"(m.ix[3]),
+                   [o4] "s"(m.ix[4]), [o5] "s"(m.ix[5]), [o6] "s"(m.ix[6]), [o7] "s"(m.ix[7]), [adj] "s"(adj)
+                 : "scc");
+}
+__device__ __forceinline__ void gather2_wait(Gathered2& g, u32x4 (&c)[4])   // drains the gathers and the coefficient loads
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]), "+v"(g.t[7]),
+                   "+s"(c[0]), "+s"(c[1]), "+s"(c[2]), "+s"(c[3]));
+}
+#define MUSTAFAR_DOT4(p, w)                                                                                          \
+    "v_dot2_f32_f16 %[a0], %[t" #p "], %[c0" #w "], %[a0]\n\tv_dot2_f32_f16 %[a1], %[t" #p "], %[c1" #w "], %[a1]\n\t"   \
+    "v_dot2_f32_f16 %[a2], %[t" #p "], %[c2" #w "], %[a2]\n\tv_dot2_f32_f16 %[a3], %[t" #p "], %[c3" #w "], %[a3]\n\t"
+// acc[h] += tile(2w) * coef(2w) + tile(2w + 1) * coef(2w + 1): the coefficient dword w of head h holds exactly that pair
+__device__ __forceinline__ void fma8_d2(const u32x4 (&c)[4], Gathered2& g, float (&acc)[4])
+{
+    asm volatile("v_or_b32 %[t0], %[t0], %[t1]\n\tv_or_b32 %[t2], %[t2], %[t3]\n\t"
+                 "v_or_b32 %[t4], %[t4], %[t5]\n\tv_or_b32 %[t6], %[t6], %[t7]\n\t"
+                 MUSTAFAR_DOT4(0, 0) MUSTAFAR_DOT4(2, 1) MUSTAFAR_DOT4(4, 2) MUSTAFAR_DOT4(6, 3)
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [t0] "+v"(g.t[0]), [t2] "+v"(g.t[2]),
+                   [t4] "+v"(g.t[4]), [t6] "+v"(g.t[6])
+                 : [t1] "v"(g.t[1]), [t3] "v"(g.t[3]), [t5] "v"(g.t[5]), [t7] "v"(g.t[7]), MUSTAFAR_COPS(0), MUSTAFAR_COPS(1),
+                   MUSTAFAR_COPS(2), MUSTAFAR_COPS(3));
+}
+
+// prefetch_meta without a divergent region (every lane loads; lanes 25.. repeat lane 24's line): the lean kernel calls it inside
+// its block loop, right in front of asm statements that own EXEC.
+__device__ __forceinline__ uint32_t prefetch_meta_all(const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t, int lane)
+{
+    const int k = lane < 24 ? lane : 24;
+    const unsigned char* a = reinterpret_cast<const unsigned char*>(bmp_t) + k * 64;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(idx_t) + (k - 16) * 64;
+    return *reinterpret_cast<const uint32_t*>(k < 16 ? a : b);
+}
+
+// One staged chunk (32 tiles) of the lean kernel; the step schedule is chunk32's.
+//   bmp_t / idx_t : the BLOCK's bitmaps / offsets (the chunk starts TOFF tiles in);  cbase + COFF + h * HS : the chunk's first
+//   coefficient of head h
+template <int ENG, int TOFF, int COFF, int HS>
+__device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
+                                           const void* __restrict__ cbase, float (&acc)[4])
+{
+    MetaB cur, nxt;
+    u32x4 c[4];
+    metab_issue_at<TOFF>(cur, bmp_t, idx_t);
+    coef4_issue_at<COFF, HS>(c, cbase);
+    metab_wait(cur);
+#define MUSTAFAR_STEP(S)                                        \
+    if constexpr (ENG == 2) {                                   \
+        Gathered2 g;                                            \
+        gather8_d2(cur, adj, g);                                \
+        gather2_wait(g, c);                                     \
+        metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
+        fma8_d2(c, g, acc);                                     \
+    } else {                                                    \
+        Gathered g;                                             \
+        gather8(cur, adj, g);                                   \
+        gather_wait<4>(g, c);                                   \
+        metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
+        fma8<4>(c, g, acc);                                     \
+    }                                                           \
+    metab_wait(nxt);                                            \
+    coef4_issue_at<COFF + 16 * (S + 1), HS>(c, cbase);          \
+    cur = nxt;
+    MUSTAFAR_STEP(0) MUSTAFAR_STEP(1) MUSTAFAR_STEP(2)
+#undef MUSTAFAR_STEP
+    if constexpr (ENG == 2) {
+        Gathered2 g;
+        gather8_d2(cur, adj, g);
+        gather2_wait(g, c);
+        fma8_d2(c, g, acc);
+    } else {
+        Gathered g;
+        gather8(cur, adj, g);
+        gather_wait<4>(g, c);
+        fma8<4>(c, g, acc);
+    }
+}
+
+// The 128 tiles of one 64-token block against the coefficients at cbase (four rows HS bytes apart).
+//   VAL = false (key):   all four chunks -> accA (lane = token);  coefficient of tile d: halfs d of the rows
+//   VAL = true  (value): chunks 0, 1 -> accA (channels 0..63), chunks 2, 3 -> accB (channels 64..127), lane = channel;
+//                        coefficient of a tile: the row's half (token % 64)
+//   bnd: the block's five chunk bounds (bnd_load), fetched by the caller ahead of time
+template <int ENG, int HS, bool VAL, int CB, int CN>   // chunks [CB, CB + CN) of the block
+__device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t lds_addr, const uint64_t* __restrict__ bmp_t,
+                                                 const uint32_t* __restrict__ idx_t, const unsigned char* __restrict__ nz_h,
+                                                 const void* __restrict__ cbase, uint32_t bnd, int lane, float (&accA)[4],
+                                                 float (&accB)[4]
+#ifdef MUSTAFAR_WAVE_TRACE
+                                                 , PhaseTrace& phase_trace_
+#endif
+                                                 )
+{
+    uint32_t i0 = bnd_get(bnd, CB);
+    const uint32_t len0 = 4u * (bnd_get(bnd, CB + 1) - i0);
+    Stage st = stage_issue(nz_h + 4ull * i0, len0, lane);
+    stage_commit(lds, st, lane, len0);
+#ifdef MUSTAFAR_WAVE_TRACE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    MUSTAFAR_PTRACE_STAMP(VAL ? 4 : 1);
+#pragma unroll
+    for (int c = CB; c < CB + CN; c++) {
+        uint32_t n0 = 0, nlen = 0;
+        if (c < CB + CN - 1) {
+            n0 = bnd_get(bnd, c + 1);
+            nlen = 4u * (bnd_get(bnd, c + 2) - n0);
+            st = stage_issue(nz_h + 4ull * n0, nlen, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+#ifdef MUSTAFAR_PROBE_HOTMETA
+        const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr);   // the fixed offsets of g_hot_idx stay inside the window
+#else
+        const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
+#endif
+        if (c == 0)      chunk32_at<ENG, 0, 0, HS>(adj, bmp_t, idx_t, cbase, accA);
+        else if (c == 1) chunk32_at<ENG, 32, 64, HS>(adj, bmp_t, idx_t, cbase, accA);
+        else if (c == 2) chunk32_at<ENG, 64, VAL ? 0 : 128, HS>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
+        else             chunk32_at<ENG, 96, VAL ? 64 : 192, HS>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
+        __builtin_amdgcn_wave_barrier();
+        if (c < CB + CN - 1) {
+            stage_commit(lds, st, lane, nlen);
+            i0 = n0;
+        }
+    }
+}
+
+// grid: x = ceil(T / 64 / (4 * tb_per_wg)) (a.tb_per_wg = consecutive 64-token blocks per WAVE here), y = kv-heads * groups / 4
+// (+ win_rows leading rows of window workgroups, as decode_onepass_kernel).  e scratch: a.e_rows is used as
+// [y][T / 64][4 heads][64 tokens] halfs (4 T halfs per y: fits the [BH, ld >= T] score buffer), every block's four segments
+// 512 contiguous bytes on scalar-cache lines of their own.
+// INVARIANT of the e round trip (vector stores, then scalar loads of the same bytes by the SAME wave): the wave waits vmcnt(0)
+// -- the stores are acknowledged by L2 -- before it issues the scalar loads; no wave scalar-reads those lines earlier in the
+// launch (a block's segments belong to one wave and are 64-byte aligned, ld_scores % 32 == 0 is checked by the host), so the
+// only stale copy the scalar cache could hold is one from an EARLIER launch reusing the scratch, and every dispatch (graph
+// nodes included) starts with an acquire that invalidates the scalar cache.  tests/test_gpu_benchshape.py replays a captured
+// step with alternating queries to hold this.
+template <int ENG>
+__global__ __launch_bounds__(kThreads) void decode_onepass_lean_kernel(
+    const uint64_t* __restrict__ k_bmp, const unsigned char* __restrict__ k_nz, const uint32_t* __restrict__ k_idx,
+    const uint32_t* __restrict__ k_nz_off, const uint64_t* __restrict__ v_bmp, const unsigned char* __restrict__ v_nz,
+    const uint32_t* __restrict__ v_idx, const uint32_t* __restrict__ v_nz_off, OneArgs a, int64_t k_bmp_stride,
+    int64_t k_idx_stride, uint32_t k_nz_stride, int64_t v_bmp_stride, int64_t v_idx_stride, uint32_t v_nz_stride)
+{
+    constexpr int G = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes];
+    static_assert(kWaves * kStageBytes >= (kWaves * 2 * 4 * 64 + 2 * kWaves * 4) * 4, "combine buffers must fit in the stage area");
+    MUSTAFAR_PTRACE_BEGIN();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wrows = a.win_rows < 0 ? -a.win_rows : a.win_rows;   // window rows lead (win_rows > 0) or trail (< 0) the grid
+    const int wy = a.win_rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
+    if (wy >= 0 && wy < wrows) {   // dense window
+        const int task = wy * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wrows) * a.nchunks) onepass_window_wg<G>(smem, win_args(a), task, gridDim.x);
+        MUSTAFAR_PTRACE_END(5);
+        return;
+    }
+    const int by = blockIdx.y - (a.win_rows > 0 ? a.win_rows : 0);
+    const int hb_per_kv = a.groups >> 2;
+    const int kvh = hb_per_kv == 1 ? by : by / hb_per_kv;
+    const int bh0 = kvh * a.groups + (by - kvh * hb_per_kv) * G;
+    const int ntb = a.T >> 6;
+    int tb = (blockIdx.x * kWaves + wave) * a.tb_per_wg;
+    const int tb_end = min(ntb, tb + a.tb_per_wg);
+    const int64_t tiles = (int64_t)ntb * kTilesPerTb;
+    const uint64_t* kb = k_bmp + (int64_t)kvh * (k_bmp_stride ? k_bmp_stride : tiles);
+    const uint32_t* ki = k_idx + (int64_t)kvh * (k_idx_stride ? k_idx_stride : tiles + 1);
+    const unsigned char* kn = k_nz + 16ull * (k_nz_stride ? (uint64_t)kvh * k_nz_stride : (uint64_t)k_nz_off[kvh]);
+    const uint64_t* vb = v_bmp + (int64_t)kvh * (v_bmp_stride ? v_bmp_stride : tiles);
+    const uint32_t* vi = v_idx + (int64_t)kvh * (v_idx_stride ? v_idx_stride : tiles + 1);
+    const unsigned char* vn = v_nz + 16ull * (v_nz_stride ? (uint64_t)kvh * v_nz_stride : (uint64_t)v_nz_off[kvh]);
+    const h16* qb = a.q + (int64_t)bh0 * kD;                     // the four q rows, 256 bytes apart
+    h16* eb = a.e_rows + (int64_t)by * ntb * (G * 64);            // this head batch's e segments, [block][4][64]
+    const h16* mrow = a.mask.ptr ? a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride : nullptr;
+    unsigned char* lds = smem + wave * kStageBytes;
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    // e = exp(x - max) * kEScale as fp16 (ENG 2: out of the subnormal range, see above); kEScaleLog2 is added to the exponent
+    constexpr float kEScaleLog2 = ENG == 2 ? 15.f : 0.f;
+
+    float m_run[G], l_run[G], acc0[G], acc1[G];   // (m_run, l_run: wave-uniform)
+#pragma unroll
+    for (int h = 0; h < G; h++) { m_run[h] = -INFINITY; l_run[h] = 0.f; acc0[h] = 0.f; acc1[h] = 0.f; }
+#pragma unroll 1
+    for (; tb < tb_end; tb++) {
+        const uint64_t* kbt = kb + (int64_t)tb * kTilesPerTb;
+        const uint32_t* kit = ki + (int64_t)tb * kTilesPerTb;
+        const uint64_t* vbt = vb + (int64_t)tb * kTilesPerTb;
+        const uint32_t* vit = vi + (int64_t)tb * kTilesPerTb;
+        // everything the block needs from memory before its streams is requested up front: metadata lines into L2, the chunk
+        // bounds of both sides, the mask column of the lane's token
+        const uint32_t pfk = prefetch_meta_all(kbt, kit, lane);
+        const uint32_t bnd_k = bnd_load(kit, lane);
+        const uint32_t pfv = prefetch_meta_all(vbt, vit, lane);
+        const uint32_t bnd_v = bnd_load(vit, lane);
+        const h16 mk = mrow ? mrow[tb * 64 + lane] : (h16)0.f;   // (mrow is wave-uniform: a scalar branch)
+        float s[G];
+#pragma unroll
+        for (int h = 0; h < G; h++) s[h] = 0.f;
+        lean_block_phase<ENG, kD * 2, false, 0, 4>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG);
+        prefetch_done(pfk);
+        MUSTAFAR_PTRACE_STAMP(2);
+        // ---- softmax step (as decode_onepass_kernel): running maximum, e -> the block's segments, running sum, rescale
+        h16* eblk = eb + (int64_t)tb * (G * 64);
+#pragma unroll
+        for (int h = 0; h < G; h++) {
+            float x = scaled((h16)s[h], a.inv_sqrt_d);        // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
+            if (mrow) x = masked(x, mk);
+            const float m_new = uniform_f(fmaxf(m_run[h], wave_max(x)));
+            const float alpha = uniform_f(__expf(m_run[h] - m_new));   // 0 for the first block (m_run = -inf)
+            const h16 e = (h16)__builtin_amdgcn_exp2f((x - m_new) * 1.44269504f + kEScaleLog2);
+            eblk[h * 64 + lane] = e;
+            l_run[h] = uniform_f(l_run[h] * alpha + wave_sum((float)e));
+            m_run[h] = m_new;
+            acc0[h] *= alpha;
+            acc1[h] *= alpha;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the e stores have reached L2 (see the invariant above)
+        MUSTAFAR_PTRACE_STAMP(3);
+        lean_block_phase<ENG, 64 * 2, true, 0, 4>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc0, acc1 MUSTAFAR_PTRACE_ARG);
+        prefetch_done(pfv);
+        MUSTAFAR_PTRACE_STAMP(5);
+    }
+    // ---- merge the four waves: common maximum, rescaled sums and outputs -> one slab per head (as decode_onepass_kernel)
+    float* red = reinterpret_cast<float*>(smem);                 // [kWaves][2G][64]
+    float* s_m = red + kWaves * 2 * G * 64;                      // [kWaves][G]
+    float* s_l = s_m + kWaves * G;                               // [kWaves][G]
+    __syncthreads();   // every wave is done with its stage window
+    if (lane < G) {
+        float mine = m_run[0];
+#pragma unroll
+        for (int h = 1; h < G; h++) mine = (lane == h) ? m_run[h] : mine;
+        s_m[wave * G + lane] = mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        float M = s_m[h];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) M = fmaxf(M, s_m[w * G + h]);
+        // a wave without blocks weighs nothing; the e scale leaves here (a power of two: exact)
+        const float scale = (m_run[h] == -INFINITY) ? 0.f : __expf(m_run[h] - M) * (ENG == 2 ? 0x1p-15f : 1.f);
+        if (lane == 0) s_l[wave * G + h] = l_run[h] * scale;
+        red[(wave * 2 * G + h) * 64 + lane]     = acc0[h] * scale;
+        red[(wave * 2 * G + G + h) * 64 + lane] = acc1[h] * scale;
+    }
+    __syncthreads();
+    float* slab_o = a.ws_o + ((int64_t)blockIdx.x * a.BH + bh0) * kD;
+    for (int o = threadIdx.x; o < 2 * G * 64; o += kThreads) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) sum += red[w * 2 * G * 64 + o];
+        const int hh = o >> 6, l = o & 63;   // hh = half * G + h
+        slab_o[(hh % G) * kD + (hh / G) * 64 + l] = sum;
+    }
+    if (threadIdx.x < G) {
+        const int h = threadIdx.x;
+        float M = s_m[h], L = s_l[h];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) { M = fmaxf(M, s_m[w * G + h]); L += s_l[w * G + h]; }
+        float* slab_ml = a.ws_ml + ((int64_t)blockIdx.x * a.BH + bh0 + h) * 2;
+        slab_ml[0] = M;
+        slab_ml[1] = L;
+    }
+    MUSTAFAR_PTRACE_END(3);
+}
+
+// The lean form at the PAIR grain: two waves share a 64-token block -- 64 channels each in the key phase (partial scores folded
+// through LDS), one 64-channel half of the output each in the value phase -- and a workgroup (two pairs) takes two blocks at a
+// time.  The whole-block form above has the fewest instructions per tile but its waves live 40 us and wait on memory with nobody
+// to cover for them (probe builds: -12 us without the stream loads, -8 us with hot metadata; the pair grain: -2 / -2): half-size
+// waves, twice as many, is the grain at which the launch is bound by instruction issue, so this is the form that runs by default.
+//   grid: x = ceil(T / 64 / a.tb_per_wg) (a.tb_per_wg = blocks per WORKGROUP, even), y as decode_onepass_lean_kernel.
+//   e round trip: the EVEN wave stores the block's four e segments and waits vmcnt(0) before the barrier; both waves then
+//   scalar-load them (the invariant stated at decode_onepass_lean_kernel, with "the same wave" read as "the same pair").
+// Compiled for 8 waves per SIMD (<= 64 vector registers; the scalar file then spills ~45 values to lanes of a vector register):
+// with the stream loads non-temporal the launch is bound by how many waves are there to cover for each other (c3, dot2 form:
+// 7 waves 45.6 us, 8 waves 44.3 us).  MUSTAFAR_LP_WAVES: experiment knob (tools/build_variant.sh).
+#ifndef MUSTAFAR_LP_WAVES
+#define MUSTAFAR_LP_WAVES 8
+#endif
+#define MUSTAFAR_LP_BOUNDS __launch_bounds__(kThreads, MUSTAFAR_LP_WAVES)
+template <int ENG>
+__global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
+    const uint64_t* __restrict__ k_bmp, const unsigned char* __restrict__ k_nz, const uint32_t* __restrict__ k_idx,
+    const uint32_t* __restrict__ k_nz_off, const uint64_t* __restrict__ v_bmp, const unsigned char* __restrict__ v_nz,
+    const uint32_t* __restrict__ v_idx, const uint32_t* __restrict__ v_nz_off, OneArgs a, int64_t k_bmp_stride,
+    int64_t k_idx_stride, uint32_t k_nz_stride, int64_t v_bmp_stride, int64_t v_idx_stride, uint32_t v_nz_stride)
+{
+    constexpr int G = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes];
+    MUSTAFAR_PTRACE_BEGIN();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wrows = a.win_rows < 0 ? -a.win_rows : a.win_rows;   // window rows lead (win_rows > 0) or trail (< 0) the grid
+    const int wy = a.win_rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
+    if (wy >= 0 && wy < wrows) {   // dense window
+        const int task = wy * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wrows) * a.nchunks) onepass_window_wg<G>(smem, win_args(a), task, gridDim.x);
+        MUSTAFAR_PTRACE_END(5);
+        return;
+    }
+    const int by = blockIdx.y - (a.win_rows > 0 ? a.win_rows : 0);
+    const int hb_per_kv = a.groups >> 2;
+    const int kvh = hb_per_kv == 1 ? by : by / hb_per_kv;
+    const int bh0 = kvh * a.groups + (by - kvh * hb_per_kv) * G;
+    const int ntb = a.T >> 6;
+    const int tb0 = blockIdx.x * a.tb_per_wg;
+    const int tb_end = min(ntb, tb0 + a.tb_per_wg);
+    const int pair = wave >> 1;
+    const bool odd = wave & 1;
+    const int64_t tiles = (int64_t)ntb * kTilesPerTb;
+    const uint64_t* kb = k_bmp + (int64_t)kvh * (k_bmp_stride ? k_bmp_stride : tiles);
+    const uint32_t* ki = k_idx + (int64_t)kvh * (k_idx_stride ? k_idx_stride : tiles + 1);
+    const unsigned char* kn = k_nz + 16ull * (k_nz_stride ? (uint64_t)kvh * k_nz_stride : (uint64_t)k_nz_off[kvh]);
+    const uint64_t* vb = v_bmp + (int64_t)kvh * (v_bmp_stride ? v_bmp_stride : tiles);
+    const uint32_t* vi = v_idx + (int64_t)kvh * (v_idx_stride ? v_idx_stride : tiles + 1);
+    const unsigned char* vn = v_nz + 16ull * (v_nz_stride ? (uint64_t)kvh * v_nz_stride : (uint64_t)v_nz_off[kvh]);
+    const h16* qb = a.q + (int64_t)bh0 * kD;
+    h16* eb = a.e_rows + (int64_t)by * ntb * (G * 64);
+    const h16* mrow = a.mask.ptr ? a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride : nullptr;
+    unsigned char* lds = smem + wave * kStageBytes;
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    // exchange area of the pair: the ODD wave's stage window (dead between the phases): 4 x 64 partial scores, then 4 factors
+    float* xch = reinterpret_cast<float*>(smem + (2 * pair + 1) * kStageBytes);
+    constexpr float kEScaleLog2 = ENG == 2 ? 15.f : 0.f;
+
+    float m_run[G], l_run[G], acc[G];   // acc: the wave's output half (even: channels 0..63, odd: 64..127); m_run, l_run live in the even wave
+#pragma unroll
+    for (int h = 0; h < G; h++) { m_run[h] = -INFINITY; l_run[h] = 0.f; acc[h] = 0.f; }
+#pragma unroll 1
+    for (int t = tb0; t < tb_end; t += kWaves / 2) {   // workgroup-uniform: every wave reaches the barriers below
+        const int tb = t + pair;
+        const bool active = tb < tb_end;                // (wave-uniform)
+        const int tbc = active ? tb : t;                // (an idle pair addresses the other pair's block and computes nothing)
+        const uint64_t* kbt = kb + (int64_t)tbc * kTilesPerTb;
+        const uint32_t* kit = ki + (int64_t)tbc * kTilesPerTb;
+        const uint64_t* vbt = vb + (int64_t)tbc * kTilesPerTb;
+        const uint32_t* vit = vi + (int64_t)tbc * kTilesPerTb;
+        h16* eblk = eb + (int64_t)tbc * (G * 64);
+        float s[G], alpha[G];
+#pragma unroll
+        for (int h = 0; h < G; h++) { s[h] = 0.f; alpha[h] = 1.f; }
+        uint32_t bnd_v = 0, pfv = 0;
+        h16 mk = (h16)0.f;
+        if (active) {
+            const uint32_t bnd_k = bnd_load(kit, lane);
+            const uint32_t pfk = prefetch_meta_all(kbt, kit, lane);
+            if (mrow) mk = mrow[tb * 64 + lane];
+            if (odd) lean_block_phase<ENG, kD * 2, false, 2, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG);
+            else     lean_block_phase<ENG, kD * 2, false, 0, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG);
+            prefetch_done(pfk);
+            // the value side's chunk bounds and metadata lines are requested HERE, a barrier and a softmax step (~2 us) in front of
+            // their use: requested at the block's start (~10 us ahead) the lines were often gone from L2 again by the time the
+            // scalar loads came for them (c3: 44.4 -> 43.7 us; without any prefetch the launch takes 62 us)
+            bnd_v = bnd_load(vit, lane);
+            pfv = prefetch_meta_all(vbt, vit, lane);
+            if (odd) {
+#pragma unroll
+                for (int h = 0; h < G; h++) xch[h * 64 + lane] = s[h];
+            }
+        }
+        MUSTAFAR_PTRACE_STAMP(2);
+        __syncthreads();
+        if (active && !odd) {
+#pragma unroll
+            for (int h = 0; h < G; h++) {
+                float x = scaled((h16)(s[h] + xch[h * 64 + lane]), a.inv_sqrt_d);   // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
+                if (mrow) x = masked(x, mk);
+                const float m_new = uniform_f(fmaxf(m_run[h], wave_max(x)));
+                alpha[h] = uniform_f(__expf(m_run[h] - m_new));   // 0 for the first block (m_run = -inf)
+                const h16 e = (h16)__builtin_amdgcn_exp2f((x - m_new) * 1.44269504f + kEScaleLog2);
+                eblk[h * 64 + lane] = e;
+                l_run[h] = uniform_f(l_run[h] * alpha[h] + wave_sum((float)e));
+                m_run[h] = m_new;
+            }
+            if (lane < G) {
+                float mine = alpha[0];
+#pragma unroll
+                for (int h = 1; h < G; h++) mine = (lane == h) ? alpha[h] : mine;
+                xch[G * 64 + lane] = mine;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the e stores have reached L2 before the pair's scalar loads
+        }
+        __syncthreads();
+        MUSTAFAR_PTRACE_STAMP(3);
+        if (active) {
+            if (odd) {
+#pragma unroll
+                for (int h = 0; h < G; h++) alpha[h] = xch[G * 64 + h];
+            }
+#pragma unroll
+            for (int h = 0; h < G; h++) acc[h] *= alpha[h];
+            // (the odd wave's LDS reads above are issued before its value phase rewrites the window: one wave, in order)
+            if (odd) lean_block_phase<ENG, 64 * 2, true, 2, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG);
+            else     lean_block_phase<ENG, 64 * 2, true, 0, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG);
+            prefetch_done(pfv);
+        }
+        MUSTAFAR_PTRACE_STAMP(5);
+    }
+    // ---- merge the two pairs: common maximum, rescaled sums and output halves -> one slab per head
+    float* red = reinterpret_cast<float*>(smem);                 // [kWaves][G][64]
+    float* s_m = red + kWaves * G * 64;                          // [2 pairs][G]
+    float* s_l = s_m + 2 * G;                                    // [2 pairs][G]
+    __syncthreads();   // every wave is done with its stage window
+    if (lane < G && !odd) {
+        float mine = m_run[0];
+#pragma unroll
+        for (int h = 1; h < G; h++) mine = (lane == h) ? m_run[h] : mine;
+        s_m[pair * G + lane] = mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        const float mw = s_m[pair * G + h];                      // the PAIR's maximum (an odd wave carries no softmax state of its own)
+        const float M = fmaxf(s_m[h], s_m[G + h]);
+        // a pair without blocks weighs nothing; the e scale leaves here (a power of two: exact)
+        const float scale = (mw == -INFINITY) ? 0.f : __expf(mw - M) * (ENG == 2 ? 0x1p-15f : 1.f);
+        if (lane == 0 && !odd) s_l[pair * G + h] = l_run[h] * scale;
+        red[(wave * G + h) * 64 + lane] = acc[h] * scale;
+    }
+    __syncthreads();
+    float* slab_o = a.ws_o + ((int64_t)blockIdx.x * a.BH + bh0) * kD;
+    for (int o = threadIdx.x; o < 2 * G * 64; o += kThreads) {
+        const int hh = o >> 6, l = o & 63;   // hh = half * G + h; waves `half` and `half + 2` hold that half
+        const int half = hh / G, h = hh % G;
+        slab_o[h * kD + half * 64 + l] = red[(half * G + h) * 64 + l] + red[((half + 2) * G + h) * 64 + l];
+    }
+    if (threadIdx.x < G) {
+        const int h = threadIdx.x;
+        float* slab_ml = a.ws_ml + ((int64_t)blockIdx.x * a.BH + bh0 + h) * 2;
+        slab_ml[0] = fmaxf(s_m[h], s_m[G + h]);
+        slab_ml[1] = s_l[h] + s_l[G + h];
+    }
+    MUSTAFAR_PTRACE_END(7);
+}
+
 inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : 1; }
 
 // FMA engine of the G = 4 kernels: 0 = VALU (v_fma_mix_f32; default, MFMA left off as the north_star asks),
@@ -1788,7 +2372,7 @@ inline int key_split(int ntb, int gy)
         g_key_split = e ? atoi(e) : 0;
     }
     if (g_key_split == 1 || g_key_split == 2) return g_key_split;
-    if (fma_engine()) return 1;   // matrix-pipe engine: one wave per block at every size (tools/sweep_forms.sh: c3 19.1 vs 20.2 us, c5 57 vs 65)
+    if (fma_engine() == 1) return 1;   // matrix-pipe engine: one wave per block at every size (tools/sweep_forms.sh: c3 19.1 vs 20.2 us, c5 57 vs 65)
     // One wave per token block unless that grid is small (<= 2048 workgroups; the chip holds 256 CUs x 6 of them, see
     // tools/wave_trace.py): then a wave's latency chain, not throughput, sets the time, and two waves per block halve it.
     return ((int64_t)((ntb + kWaves - 1) / kWaves) * gy <= 2048) ? 2 : 1;
@@ -1843,12 +2427,32 @@ inline int onepass_target_wgs(bool pair)
     }
     return g_onepass_wgs > 0 ? g_onepass_wgs : (pair ? 4096 : 0);   // (VALU pair form: flat from 4096 workgroups up at c3; 0: fixed blocks per workgroup)
 }
+// GQA-4 one-pass launches on the vector engines: MUSTAFAR_ONEPASS_LEAN=2 (default) the lean kernel at the pair grain, 1 the lean
+// kernel with whole blocks per wave, 0 the round-2 pair form; MUSTAFAR_LEAN_TBW=n: blocks per wave (1) / block pairs per
+// workgroup (2) instead of the automatic choice (raised when the slabs would not fit).
+int g_lean = -1, g_lean_tbw = -1, g_lean_win_last = 0;
+inline int onepass_lean()
+{
+    if (g_lean < 0) {
+        const char* e = getenv("MUSTAFAR_ONEPASS_LEAN");
+        g_lean = !e ? 2 : (e[0] == '0') ? 0 : (e[0] == '1') ? 1 : 2;
+    }
+    return g_lean;
+}
+inline int onepass_lean_tbw()
+{
+    if (g_lean_tbw < 0) {
+        const char* e = getenv("MUSTAFAR_LEAN_TBW");
+        g_lean_tbw = e ? atoi(e) : 0;
+    }
+    return g_lean_tbw;
+}
 int g_engine = -1;
 inline int fma_engine()
 {
     if (g_engine < 0) {
         const char* e = getenv("MUSTAFAR_FMA_ENGINE");
-        g_engine = (e && (e[0] == 'm' || e[0] == 'M' || e[0] == '1')) ? 1 : 0;
+        g_engine = !e ? 0 : (e[0] == 'm' || e[0] == 'M' || e[0] == '1') ? 1 : (e[0] == 'd' || e[0] == 'D' || e[0] == '2') ? 2 : 0;
     }
     return g_engine;
 }
@@ -1857,7 +2461,7 @@ inline bool onepass_enabled(int64_t kv_heads, int T)
 {
     const int mode = onepass_mode();
     if (mode != 2) return mode == 1;
-    return fma_engine() || kv_heads * T <= 768000;   // VALU engine: c2, c3 one-pass, c4 / c5 two launches; matrix-pipe engine: always one-pass
+    return fma_engine() == 1 || kv_heads * T <= 768000;   // VALU engine: c2, c3 one-pass, c4 / c5 two launches; matrix-pipe engine: always one-pass
 }
 
 // Optional live timing of the two SpMV kernels inside mustafar_decode_attention (bench.py's roofline leg): HIP
@@ -1898,7 +2502,7 @@ void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, co
     } while (0)
     switch (G) {
         case 4:
-            if (fma_engine()) MUSTAFAR_LK(4, true);
+            if (fma_engine() == 1) MUSTAFAR_LK(4, true);
             else              MUSTAFAR_LK(4, false);
             break;
         case 2: MUSTAFAR_LK(2, false); break;
@@ -1918,7 +2522,7 @@ inline int value_split()
         g_value_split = e ? (atoi(e) == 1 ? 1 : 2) : 0;
     }
     if (g_value_split) return g_value_split;
-    return fma_engine() ? 1 : 2;   // the MFMA form needs > 80 VGPRs: 8-wave workgroups would drop to 4 waves per SIMD
+    return fma_engine() == 1 ? 1 : 2;   // the MFMA form needs > 80 VGPRs: 8-wave workgroups would drop to 4 waves per SIMD
 }
 inline int value_tb_stride() { return value_split() == 2 ? kValueWaves / 2 : kWaves; }   // token blocks in flight per workgroup
 
@@ -1946,7 +2550,7 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
     } while (0)
     switch (G) {
         case 4:
-            if (fma_engine()) MUSTAFAR_LV(4, true);
+            if (fma_engine() == 1) MUSTAFAR_LV(4, true);
             else              MUSTAFAR_LV(4, false);
             break;
         case 2: MUSTAFAR_LV(2, false); break;
@@ -2087,7 +2691,47 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     if (T > 0 && onepass_enabled(Batch_Size / groups, T) && (ld_scores & 31) == 0) {
         // ---- one-pass form: every wave runs key phase -> softmax step -> value phase on its token blocks; slabs merged per row
         const int ntb = T / 64;
-        const bool pair = !fma_engine() || G != 4;                      // two waves per block unless the matrix-pipe engine runs
+        if (G == 4 && fma_engine() != 1 && onepass_lean() != 0) {
+            // lean forms (GQA-4, vector engines).  2 (default): pair grain -- two waves per block, two blocks per workgroup at a
+            // time; 1: a wave owns `tbw` consecutive whole blocks.  Four waves merge into one slab either way.
+            const bool lp = onepass_lean() == 2;
+            const int nchunks = (window_capacity + kOneWinChunk - 1) / kOneWinChunk;
+            int per_wg;   // 64-token blocks per workgroup
+            if (lp) {
+                const int want = (onepass_target_wgs(true) + gy - 1) / gy;
+                per_wg = ((ntb + want - 1) / want + 1) / 2 * 2;
+                if (onepass_lean_tbw() > 0) per_wg = 2 * onepass_lean_tbw();
+            } else {
+                per_wg = kWaves * (onepass_lean_tbw() > 0 ? onepass_lean_tbw() : 1);
+            }
+            const int step = lp ? 2 : kWaves;
+            while ((ntb + per_wg - 1) / per_wg + nchunks > kMaxSlabs) per_wg += step;
+            const int S1 = (ntb + per_wg - 1) / per_wg;
+            float* ws_o = static_cast<float*>(workspace);
+            float* ws_ml = ws_o + (int64_t)(S1 + nchunks) * Batch_Size * kD;
+            const int win_rows = (gy * nchunks + S1 - 1) / S1;
+            const OneArgs a{qh, sc, ws_o, ws_ml, kwin, vwin, knew, vnew, window_len_extra, mask, T, groups, Batch_Size, lp ? per_wg : per_wg / kWaves,
+                            ld_scores, window_len, window_capacity, nchunks, g_lean_win_last ? -win_rows : win_rows, inv_sqrt_d0};
+            const dim3 grid(S1, gy + win_rows);
+            hipEvent_t e0 = prof ? g_prof.ev[4 * g_prof.n] : nullptr, e1 = prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr;
+            auto kz = static_cast<const unsigned char*>(kc.nz), vz = static_cast<const unsigned char*>(vc.nz);
+#define MUSTAFAR_LL(KERNEL)                                                                                                           \
+    hipExtLaunchKernelGGL(KERNEL, grid, dim3(kThreads), 0, st, e0, e1, 0, kc.bmp, kz, kc.idx, kc.nz_offset,                            \
+                          vc.bmp, vz, vc.idx, vc.nz_offset, a, kc.bmp_head_stride, kc.idx_head_stride, (uint32_t)kc.nz_head_stride,    \
+                          vc.bmp_head_stride, vc.idx_head_stride, (uint32_t)vc.nz_head_stride)
+            if (lp) {
+                if (fma_engine() == 2) MUSTAFAR_LL((decode_onepass_leanpair_kernel<2>));
+                else                   MUSTAFAR_LL((decode_onepass_leanpair_kernel<0>));
+            } else {
+                if (fma_engine() == 2) MUSTAFAR_LL((decode_onepass_lean_kernel<2>));
+                else                   MUSTAFAR_LL((decode_onepass_lean_kernel<0>));
+            }
+#undef MUSTAFAR_LL
+            if (prof) { g_prof.onepass++; g_prof.n++; }
+            onepass_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, S1 + nchunks, static_cast<h16*>(out), Batch_Size);
+            return (int)hipGetLastError();
+        }
+        const bool pair = fma_engine() != 1 || G != 4;                      // two waves per block unless the matrix-pipe engine runs
         const int round = pair ? kWaves / 2 : kWaves;                     // token blocks a workgroup has in flight
         // workgroups of the SpMV part: ~onepass_target_wgs(), every workgroup whole rounds of its waves (Split_K only sizes the
         // workspace here: the slab count below never exceeds it by more than the rounding)
@@ -2129,7 +2773,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                           vc.bmp_head_stride, vc.idx_head_stride, (uint32_t)vc.nz_head_stride)
             switch (G) {
                 case 4:
-                    if (fma_engine()) MUSTAFAR_L1(4, true);
+                    if (fma_engine() == 1) MUSTAFAR_L1(4, true);
                     else              MUSTAFAR_L1(4, false);
                     break;
                 case 2: MUSTAFAR_L1(2, false); break;
@@ -2271,7 +2915,7 @@ int mustafar_counter_add(void* stream, int32_t* counter, int delta)
 
 int mustafar_set_fma_engine(int engine)
 {
-    if (engine != 0 && engine != 1) return MUSTAFAR_EINVAL;
+    if (engine < 0 || engine > 2) return MUSTAFAR_EINVAL;
     g_engine = engine;
     return 0;
 }
@@ -2286,6 +2930,20 @@ int mustafar_set_onepass(int mode)
 }
 
 int mustafar_get_onepass(void) { return onepass_mode(); }
+
+// Tuning knobs of the experiment scripts (tools/): 0 = lean one-pass form on / off, 1 = blocks per wave of the lean form
+// (0 = automatic), 2 = workgroup target of the pair form (0 = automatic).  Not part of the operator interface.
+int mustafar_tune(int knob, int value)
+{
+    if (value < 0) return MUSTAFAR_EINVAL;
+    switch (knob) {
+        case 0: g_lean = value > 2 ? 2 : value; return 0;
+        case 1: g_lean_tbw = value; return 0;
+        case 2: g_onepass_wgs = value; return 0;
+        case 3: g_lean_win_last = value ? 1 : 0; return 0;
+        default: return MUSTAFAR_EINVAL;
+    }
+}
 
 #ifdef MUSTAFAR_WAVE_TRACE
 // Tool-only (tools/wave_trace.py): records go to `buf` (4 x u64 each, `cap` slots; zero it first).

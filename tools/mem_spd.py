@@ -133,8 +133,10 @@ class Generator:
         return out, state
 
 
-def run(a, api, dev):
+def run(a, api, dev, keep=None):
     gen = Generator(a, api, dev)
+    if keep is not None:
+        keep[api] = gen                                # (tests/test_gpu_mem_spd.py rebuilds the dense answer from the generator's tensors)
     torch.cuda.synchronize(dev)
     gen.generate()                                     # warm-up (mem_spd_test.py:81-83)
     torch.cuda.synchronize(dev)
@@ -169,7 +171,7 @@ def run(a, api, dev):
     return res, out
 
 
-def main(argv=None):
+def main(argv=None, keep=None):
     a = parse(argv)
     if a.checkpoint is not None and not os.path.isdir(a.checkpoint):
         raise SystemExit(f"--checkpoint expects a local directory (got {a.checkpoint!r}); hub names are not accepted: there is no network")
@@ -178,7 +180,7 @@ def main(argv=None):
     dev = torch.device("cuda:0")
     results, outs = [], {}
     for api in a.api:
-        res, out = run(a, api, dev)
+        res, out = run(a, api, dev, keep)
         results.append(res)
         outs[api] = out
         print(json.dumps(res), flush=True)
