@@ -19,7 +19,7 @@ child processes itself (before this process touches the GPU).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects, plus:
   self_check     the timed call sequence against the two reference entry points, every layer, before the timed region
                  (a mismatch ends the run with a non-zero exit code and no line)
-  roofline_mfma  the same measurement on the opt-in matrix-pipe FMA engine
+  roofline_fma_mix / roofline_mfma   the same measurement on the exact v_fma_mix engine / the opt-in matrix-pipe engine
   configs        c2 / c4 / c5 sub-results (N = 1 only)
   tokens_per_sec_incl_trigger   >= 256 consecutive steps, the 256-token compression trigger included
 """
@@ -408,19 +408,19 @@ def run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib):
            "steps": steps, "self_check_excess": round(excess, 3),
            "kernel": rl["kernel"], "kernel_us": rl["avg_launch_us"], "roofline_frac": rl["frac"], "roofline_achieved_GBps": rl["achieved"], "kv_bytes_reference_layout": int(w.ref_kv_bytes), "dense_kv_bytes": int(w.dense_bytes),
            "arena_bytes_in_use": w.extra.get("arena_bytes_in_use"), "arena_bytes_reserved": w.extra.get("arena_bytes_reserved")}
-    if (w.Hq // w.Hkv) % 4 == 0:   # the same leg on the matrix-pipe engine (opt-in; GQA-4 kernels only)
-        from mustafar_amd import _lib
-        _lib.check(lib.mustafar_set_fma_engine(1), "set_fma_engine")
-        try:
-            ex = w.self_check()
-            if not ex <= 1.0:
-                raise SystemExit(f"bench.py: self-check FAILED at {name} on the MFMA engine: {ex:.2f}x the fp16 bound")
-            dt_e, (ku, vu, ne) = w.timed_graph(steps, 2)
-            rm = w.roofline(ku, vu, ne, traffic_file=False)
-        finally:
-            _lib.check(lib.mustafar_set_fma_engine(0), "set_fma_engine")
-        out["fma_engine_mfma"] = {"value": round(world * w.batch * steps / dt_e, 2), "ms_per_step": round(dt_e / steps * 1e3, 4), "self_check_excess": round(ex, 3),
-                                  "kernel": rm["kernel"], "kernel_us": rm["avg_launch_us"], "roofline_frac": rm["frac"], "roofline_achieved_GBps": rm["achieved"]}
+    if (w.Hq // w.Hkv) % 4 == 0:   # the same leg on the other two engines (GQA-4 kernels only), chosen per instance (cfg.engine -> flags)
+        for eng, key in (("valu", "fma_engine_fma_mix"), ("mfma", "fma_engine_mfma")):
+            w.cfg.engine = eng
+            try:
+                ex = w.self_check()
+                if not ex <= 1.0:
+                    raise SystemExit(f"bench.py: self-check FAILED at {name} on engine {eng}: {ex:.2f}x the fp16 bound")
+                dt_e, (ku, vu, ne) = w.timed_graph(steps, 2)
+                rm = w.roofline(ku, vu, ne, traffic_file=False)
+            finally:
+                w.cfg.engine = None
+            out[key] = {"value": round(world * w.batch * steps / dt_e, 2), "ms_per_step": round(dt_e / steps * 1e3, 4), "self_check_excess": round(ex, 3),
+                        "kernel": rm["kernel"], "kernel_us": rm["avg_launch_us"], "roofline_frac": rm["frac"], "roofline_achieved_GBps": rm["achieved"]}
     del w
     torch.cuda.empty_cache()
     return out
@@ -493,20 +493,26 @@ def main():
                            "key_call_us": round(ku, 2), "value_call_us": round(vu, 2),
                            "note": API_NOTE[api] + ("; eager (no graph)" if api == "fused" else "")}
 
-    # ---- second engine: the matrix pipe as a 4-wide FMA unit (opt-in; the north_star leaves MFMA off) -------------------
-    engine_extra, roofline_mfma = None, None
+    # ---- the other two engines on the same call sequence and timed region, chosen per instance (MustafarConfig.engine -> the call's
+    # `flags`): fma_mix = exact fp16 products (the round-1/2 default), mfma = the matrix pipe as a 4-wide FMA unit (opt-in; the
+    # north_star leaves MFMA off)
+    engine_legs, roofline_legs = {}, {}
     if use_graph and w.Hq // w.Hkv >= 4 and (w.Hq // w.Hkv) % 4 == 0:
-        _lib.check(lib.mustafar_set_fma_engine(1), "set_fma_engine")
-        ex = w.self_check()
-        if not ex <= 1.0:
-            raise SystemExit(f"bench.py: self-check FAILED on the MFMA engine: {ex:.2f}x the fp16 bound")
-        dt_e, (ku, vu, ne) = w.timed_graph(a.steps, a.warmup)
-        _lib.check(lib.mustafar_set_fma_engine(0), "set_fma_engine")
-        roofline_mfma = w.roofline(ku, vu, ne, traffic_file=False)
-        engine_extra = {"value": round(world * w.batch * a.steps / dt_e, 2), "unit": "tokens/s", "ms_per_step": round(dt_e / a.steps * 1e3, 4),
-                        "steps": a.steps, "key_kernel_us": round(ku, 2), "value_kernel_us": round(vu, 2), "self_check_excess": round(ex, 3),
-                        "note": "same fused call sequence, same timed region, with MUSTAFAR_FMA_ENGINE=mfma (v_mfma_f32_4x4x4_16B_f16 as a 4-wide FMA unit; "
-                                "nothing dense is built); opt-in, off by default"}
+        for eng, note in (("valu", "v_fma_mix_f32 per tile and head: exact fp16 x fp16 products, fp16 subnormals included"),
+                          ("mfma", "v_mfma_f32_4x4x4_16B_f16 as a 4-wide FMA unit (nothing dense is built); opt-in, off by default")):
+            w.cfg.engine = eng
+            try:
+                ex = w.self_check()
+                if not ex <= 1.0:
+                    raise SystemExit(f"bench.py: self-check FAILED on engine {eng}: {ex:.2f}x the fp16 bound")
+                dt_e, (ku, vu, ne) = w.timed_graph(a.steps, a.warmup)
+            finally:
+                w.cfg.engine = None
+            roofline_legs[eng] = w.roofline(ku, vu, ne, traffic_file=False)
+            engine_legs[eng] = {"value": round(world * w.batch * a.steps / dt_e, 2), "unit": "tokens/s", "ms_per_step": round(dt_e / a.steps * 1e3, 4),
+                                "steps": a.steps, "key_kernel_us": round(ku, 2), "value_kernel_us": round(vu, 2), "self_check_excess": round(ex, 3),
+                                "note": "same fused call sequence, same timed region; " + note}
+    engine_extra, roofline_mfma = engine_legs.get("mfma"), roofline_legs.get("mfma")
 
     # ---- >= 256 consecutive steps: the 256-token compression trigger (prune + compress + in-place append) included --------
     trig = None
@@ -558,7 +564,8 @@ def main():
         "config": {"workload": label, "id": a.config, "layers": a.layers, "q_heads": Hq, "kv_heads": Hkv, "head_dim": D,
                    "sparsity": s, "seq_len": L, "compressed_tokens": T, "batch_per_gpu": batch, "residual_length": R,
                    "api": a.api, "api_note": API_NOTE[a.api] + ("; the whole step captured once in a hipGraph and replayed" if use_graph else "") + ("; structure run: " + roofline["kernel"] if a.api == "fused" else ""),
-                   "fma_engine": "valu (v_fma_mix_f32; MFMA off)", "parallelism": f"replicas x{world}"},
+                   "fma_engine": "dot2 (v_dot2_f32_f16 on pairs of tiles in the GQA-4 one-pass launch, v_fma_mix_f32 elsewhere; MFMA off)",
+                   "parallelism": f"replicas x{world}"},
         "self_check": {"passed": True, "excess_over_fp16_bound": round(excess, 3),
                        "what": "every layer's output of the timed call sequence (fused entry point, arena cache) vs the two reference entry "
                                "points with PyTorch glue on the same inputs; bound = 2 ulp of the output scale + 1e-4"},
@@ -569,8 +576,8 @@ def main():
         "allocator_peak_bytes": int(alloc_peak),
         "allocator_note": "peak of the whole bench process: the reference-layout caches kept for the other call sequences and the self-check + "
                           "the appendable (arena) copy the timed fused leg runs on + transients",
-        "roofline": roofline, "roofline_mfma": roofline_mfma, "cpu_baseline": cpu, "other_call_sequences": others,
-        "fma_engine_mfma": engine_extra, "tokens_per_sec_incl_trigger": trig, "configs": sub,
+        "roofline": roofline, "roofline_fma_mix": roofline_legs.get("valu"), "roofline_mfma": roofline_mfma, "cpu_baseline": cpu,
+        "other_call_sequences": others, "fma_engine_fma_mix": engine_legs.get("valu"), "fma_engine_mfma": engine_extra, "tokens_per_sec_incl_trigger": trig, "configs": sub,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:

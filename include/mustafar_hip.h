@@ -111,14 +111,22 @@ int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int
  *                per `heads_per_mask_row` consecutive score rows (the reference mask is [bsz, 1, 1, kv_len]: stride kv_len,
  *                heads_per_mask_row = q heads).  Applied exactly as the hook does: fp16(score / sqrt(d)) + mask in fp16,
  *                max with finfo(fp16).min, then the fp32 softmax.  Rows need no alignment.
+ *   flags        0, or this call's own choice of FMA engine and launch structure (MUSTAFAR_FLAG_*), which then overrides the
+ *                process defaults (environment / mustafar_set_fma_engine / mustafar_set_onepass) for this call only: two hook
+ *                instances in one process can run different engines.  Undefined bits are rejected.
  */
+#define MUSTAFAR_FLAG_ENGINE_FMA_MIX 1u  /* v_fma_mix_f32 per tile and head (exact products, fp16 subnormals included) */
+#define MUSTAFAR_FLAG_ENGINE_MFMA    2u  /* v_mfma_f32_4x4x4_16B_f16 as a 4-wide FMA unit (GQA-4) */
+#define MUSTAFAR_FLAG_ENGINE_DOT2    3u  /* v_dot2_f32_f16 on pairs of tiles (GQA-4 one-pass form; the default) */
+#define MUSTAFAR_FLAG_TWO_LAUNCH     (1u << 4)  /* key SpMV -> softmax rows -> value SpMV -> sum */
+#define MUSTAFAR_FLAG_ONE_PASS       (2u << 4)  /* one launch + slab merge */
 int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k_nz, const uint32_t* k_idx,
                               const uint32_t* k_nz_offset, const uint64_t* v_bmp, const void* v_nz, const uint32_t* v_idx,
                               const uint32_t* v_nz_offset, const void* q, void* k_window, void* v_window, const void* k_new,
                               const void* v_new, int window_len, int window_capacity, void* scores, int ld_scores, void* out,
                               void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
                               const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
-                              int heads_per_mask_row);
+                              int heads_per_mask_row, uint32_t flags);
 int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value_groups, int Split_K);
 
 /*
@@ -146,7 +154,7 @@ int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_ca
                                    int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
                                    int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
                                    const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
-                                   int heads_per_mask_row);
+                                   int heads_per_mask_row, uint32_t flags);
 
 /*
  * In-place append of t new (already pruned) tokens per head behind the `old_tokens` a view holds: the cache-append
@@ -196,9 +204,17 @@ int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int
 int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int64_t head_stride, int Bp, int len, int drop);
 
 /*
- * FMA engine of the GQA-4 SpMV kernels: 0 = VALU v_fma_mix_f32 (default; MFMA left off as the north_star asks),
- * 1 = v_mfma_f32_4x4x4_16B_f16 used as a 4-wide FMA unit (opt-in; also MUSTAFAR_FMA_ENGINE=mfma in the environment).
- * Same inputs, same outputs (fp32 accumulation either way).
+ * FMA engine, process default (a fused call may carry its own in `flags`):
+ *   2 = v_dot2_f32_f16 on pairs of tiles (default; GQA-4 one-pass decode launches).  One instruction does two tiles of one head, so
+ *       the FMA phase costs 2 + 1.5 cheap instead of 4 vector instructions per tile.  For normal fp16 inputs the instruction is a
+ *       two-term dot product with ONE rounding; a product with an fp16-SUBNORMAL input can lose up to its whole value (measured on
+ *       gfx950, tools/ubench/dot2_asm_numerics.hip: under 1 % of such products do; never more than the product itself).  So the
+ *       softmax weights travel scaled by 2^15 (weights down to 2^-29 stay normal; exactly undone when the slab is written), and a
+ *       non-zero K / V / q element below 2^-14 contributes with an absolute error of at most 6.1e-5 x |coefficient| -- inside the
+ *       fp16 rounding of the scores and outputs.  Kernels without a dot2 form (the two reference entry points, G < 4) run engine 0.
+ *   0 = v_fma_mix_f32 per tile and head (exact fp16 x fp16 products in fp32, subnormals included)
+ *   1 = v_mfma_f32_4x4x4_16B_f16 used as a 4-wide FMA unit (opt-in: the north_star leaves MFMA off)
+ * Environment: MUSTAFAR_FMA_ENGINE=dot2|valu|mfma.  fp32 accumulation in every engine.
  */
 int mustafar_set_fma_engine(int engine);
 int mustafar_get_fma_engine(void);
@@ -213,6 +229,10 @@ int mustafar_get_fma_engine(void);
  */
 int mustafar_set_onepass(int mode);
 int mustafar_get_onepass(void);
+/* What the last fused call on the calling thread launched: FMA engine that ran (0 v_fma_mix_f32, 1 matrix pipe, 2 v_dot2_f32_f16)
+ * | structure << 4 (0 two launches, 1 one-pass) | one-pass form << 8 (0 round-2 forms, 1 lean whole-block, 2 lean pair grain);
+ * -1 before the first call.  For tests and tools: a call's `flags` and the process defaults can be checked against what ran. */
+int mustafar_last_decode_choice(void);
 /* Tuning knobs for the measurement scripts under tools/ (launch shapes of the one-pass forms); not an operator interface. */
 int mustafar_tune(int knob, int value);
 

@@ -30,9 +30,9 @@ SIGNATURES = {
     "mustafar_value_pick_split_k": (_i32, [_i32] * 5),
     "mustafar_value_workspace_bytes": (_i64, [_i32] * 6),
     "mustafar_decode_attention": (_i32, [_vp] * 14 + [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_float, _vp,
-                                         _vp, _i64, _i32]),
+                                         _vp, _i64, _i32, ctypes.c_uint32]),
     "mustafar_decode_attention_view": (_i32, [_vp, _view_p, _view_p] + [_vp] * 5 + [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
-                                              ctypes.c_float, _vp, _vp, _i64, _i32]),
+                                              ctypes.c_float, _vp, _vp, _i64, _i32, ctypes.c_uint32]),
     "mustafar_cache_append_bitmap_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32, _vp]),
     "mustafar_cache_append_bitmap_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32, _vp]),
     "mustafar_cache_append_pack_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32]),
@@ -46,6 +46,7 @@ SIGNATURES = {
     "mustafar_get_fma_engine": (_i32, []),
     "mustafar_set_onepass": (_i32, [_i32]),
     "mustafar_get_onepass": (_i32, []),
+    "mustafar_last_decode_choice": (_i32, []),
     "mustafar_tune": (_i32, [_i32, _i32]),
     "mustafar_profile_begin": (_i32, [_i32]),
     "mustafar_profile_end": (_i32, [_vp, _vp, _vp]),
@@ -55,6 +56,10 @@ SIGNATURES = {
     "mustafar_compress_pack_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mustafar_compress_pack_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
 }
+
+# `flags` of the fused entry points (MUSTAFAR_FLAG_* in include/mustafar_hip.h)
+ENGINE_FLAGS = {None: 0, "default": 0, "valu": 1, "fma_mix": 1, "mfma": 2, "dot2": 3}
+STRUCTURE_FLAGS = {None: 0, "auto": 0, "two_launch": 1 << 4, "one_pass": 2 << 4}
 
 _lib = None
 

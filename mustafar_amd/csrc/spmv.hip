@@ -1858,11 +1858,12 @@ __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __rest
 //   * FMA phase (ENG): 0 = four v_fma_mix_f32 per tile under EXEC = bitmap (as chunk32), or
 //     2 = v_dot2_f32_f16 on PAIRS of tiles: the gathers run under EXEC = bitmap into zeroed registers (even tile -> low half,
 //     odd tile -> high half through ds_read_u16_d16_hi, packed by one full-rate v_or_b32), then ONE v_dot2 per head and pair:
-//     per tile 3 + 2 half-rate and 1.5 full-rate vector instructions instead of 3 + 4.  v_dot2_f32_f16 flushes fp16
-//     SUBNORMAL inputs (tools/ubench/dot2_numerics.hip); the softmax weights therefore travel scaled by 2^15 (e in
-//     (2^-29, 1] stays normal; the factor cancels between the output and the denominator and is removed exactly when the slab
-//     is written), and a non-zero K / V / q element below 2^-14 counts as zero -- an absolute error below 6.1e-5 x |coefficient|
-//     per such element, far inside the fp16 rounding of the scores and outputs themselves.
+//     per tile 3 + 2 half-rate and 1.5 full-rate vector instructions instead of 3 + 4.  A v_dot2_f32_f16 product with an fp16
+//     SUBNORMAL input can lose up to its whole value (tools/ubench/dot2_asm_numerics.hip: the instruction as issued here, under
+//     1 % of such products); the softmax weights therefore travel scaled by 2^15 (e in (2^-29, 1] stays normal; the factor
+//     cancels between the output and the denominator and is removed exactly when the slab is written), and a non-zero
+//     K / V / q element below 2^-14 contributes with an absolute error of at most 6.1e-5 x |coefficient|, far inside the fp16
+//     rounding of the scores and outputs themselves.
 template <int TOFF>
 __device__ __forceinline__ void metab_issue_at(MetaB& m, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx)
 {
@@ -2408,9 +2409,15 @@ inline bool window_rows_last(int side)
 // counts while a launch is tens of microseconds, and loses once the launches are long (its pair form pays two barriers per
 // block).  Matrix-pipe engine (e stays in LDS, no barriers): c3 5200 vs 4590, c4 1676 vs 1543, c5 3672 vs 3391 -- one-pass
 // at every size.  `by size` = that rule.
+// Process DEFAULTS live in the g_* variables (environment, mustafar_set_fma_engine / mustafar_set_onepass); a fused call may carry
+// its own choice in its `flags` argument, in force for that call only (t_engine / t_onepass: set and cleared by decode_attention
+// on the calling thread).
+thread_local int t_engine = -1, t_onepass = -1;
+thread_local int t_last_choice = -1;   // what the last fused call on this thread launched: engine | structure << 4 | one-pass form << 8
 int g_onepass = -1;
 inline int onepass_mode()
 {
+    if (t_onepass >= 0) return t_onepass;
     if (g_onepass < 0) {
         const char* e = getenv("MUSTAFAR_ONEPASS");
         g_onepass = !e ? 2 : e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
@@ -2450,9 +2457,10 @@ inline int onepass_lean_tbw()
 int g_engine = -1;
 inline int fma_engine()
 {
+    if (t_engine >= 0) return t_engine;
     if (g_engine < 0) {
         const char* e = getenv("MUSTAFAR_FMA_ENGINE");
-        g_engine = !e ? 0 : (e[0] == 'm' || e[0] == 'M' || e[0] == '1') ? 1 : (e[0] == 'd' || e[0] == 'D' || e[0] == '2') ? 2 : 0;
+        g_engine = !e ? 2 : (e[0] == 'm' || e[0] == 'M' || e[0] == '1') ? 1 : (e[0] == 'v' || e[0] == 'V' || e[0] == '0') ? 0 : 2;
     }
     return g_engine;
 }
@@ -2461,7 +2469,7 @@ inline bool onepass_enabled(int64_t kv_heads, int T)
 {
     const int mode = onepass_mode();
     if (mode != 2) return mode == 1;
-    return fma_engine() == 1 || kv_heads * T <= 768000;   // VALU engine: c2, c3 one-pass, c4 / c5 two launches; matrix-pipe engine: always one-pass
+    return true;   // (decode_attention narrows this for the round-2 pair form, the only one that loses to two launches at c4 / c5)
 }
 
 // Optional live timing of the two SpMV kernels inside mustafar_decode_attention (bench.py's roofline leg): HIP
@@ -2563,7 +2571,7 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
 
 extern "C" {
 
-int mustafar_abi_version(void) { return 101; }
+int mustafar_abi_version(void) { return 102; }
 
 int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
                    const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,
@@ -2661,9 +2669,16 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                      void* v_window, const void* k_new, const void* v_new, int window_len, int window_capacity, void* scores,
                      int ld_scores, void* out, void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups,
                      float sqrt_d, const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
-                     int heads_per_mask_row)
+                     int heads_per_mask_row, uint32_t flags)
 {
     const int groups = num_key_value_groups;
+    // the call's own engine / structure (mustafar_hip.h: MUSTAFAR_FLAG_*), in force until this function returns
+    const uint32_t f_eng = flags & 7u, f_str = (flags >> 4) & 3u;
+    if (f_eng > 3u || f_str > 2u || (flags & ~0x37u)) return MUSTAFAR_EINVAL;
+    struct Override {
+        Override(int e, int o) { t_engine = e; t_onepass = o; }
+        ~Override() { t_engine = -1; t_onepass = -1; }
+    } override_(f_eng == 1 ? 0 : f_eng == 2 ? 1 : f_eng == 3 ? 2 : -1, f_str == 1 ? 0 : f_str == 2 ? 1 : -1);
     if (attention_mask && (heads_per_mask_row < 1 || Batch_Size % heads_per_mask_row || mask_row_stride < 0)) return MUSTAFAR_EINVAL;
     const MaskArg mask{static_cast<const h16*>(attention_mask), mask_row_stride, heads_per_mask_row > 0 ? heads_per_mask_row : 1};
     if (T < 0 || (T & 63) || groups < 1 || Batch_Size < 1 || Batch_Size % groups || window_len < 1 ||
@@ -2688,18 +2703,30 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     auto knew = static_cast<const h16*>(k_new);
     auto vnew = static_cast<const h16*>(v_new);
     const float inv_sqrt_d0 = (float)(1.0 / (double)sqrt_d);
-    if (T > 0 && onepass_enabled(Batch_Size / groups, T) && (ld_scores & 31) == 0) {
+    // Structure by size (mode 2): the lean kernels (GQA-4, vector engines) and the matrix-pipe form run one-pass at every size
+    // (round 3, tokens/s one-pass vs two launches -- dot2: c3 5110 vs 4180, c4 1540 vs 1350, c5 3470 vs 3130; fma_mix: c4 1416 vs
+    // 1353, c5 3111 vs 3131); the round-2 pair form (G < 4) while kv-heads x T is small (c2: 1650 vs 1310)
+    const bool lean_form = G == 4 && fma_engine() != 1 && onepass_lean() != 0;
+    const bool small = (int64_t)(Batch_Size / groups) * T <= 768000;
+    if (T > 0 && onepass_enabled(Batch_Size / groups, T) && (onepass_mode() == 1 || lean_form || fma_engine() == 1 || small) &&
+        (ld_scores & 31) == 0) {
         // ---- one-pass form: every wave runs key phase -> softmax step -> value phase on its token blocks; slabs merged per row
         const int ntb = T / 64;
-        if (G == 4 && fma_engine() != 1 && onepass_lean() != 0) {
+        if (lean_form) {
             // lean forms (GQA-4, vector engines).  2 (default): pair grain -- two waves per block, two blocks per workgroup at a
             // time; 1: a wave owns `tbw` consecutive whole blocks.  Four waves merge into one slab either way.
             const bool lp = onepass_lean() == 2;
             const int nchunks = (window_capacity + kOneWinChunk - 1) / kOneWinChunk;
             int per_wg;   // 64-token blocks per workgroup
             if (lp) {
-                const int want = (onepass_target_wgs(true) + gy - 1) / gy;
-                per_wg = ((ntb + want - 1) / want + 1) / 2 * 2;
+                // one block pair per workgroup while that makes <= 4096 workgroups (c3: 3968), two beyond (c4 74.8 vs 78.9 us with
+                // four, c5 139.6 vs 145.5 with one); MUSTAFAR_ONEPASS_WGS / MUSTAFAR_LEAN_TBW override
+                per_wg = (int64_t)((ntb + 1) / 2) * gy <= 4096 ? 2 : 4;
+                (void)onepass_target_wgs(true);   // (reads MUSTAFAR_ONEPASS_WGS once)
+                if (g_onepass_wgs > 0) {
+                    const int want = (g_onepass_wgs + gy - 1) / gy;
+                    per_wg = ((ntb + want - 1) / want + 1) / 2 * 2;
+                }
                 if (onepass_lean_tbw() > 0) per_wg = 2 * onepass_lean_tbw();
             } else {
                 per_wg = kWaves * (onepass_lean_tbw() > 0 ? onepass_lean_tbw() : 1);
@@ -2729,6 +2756,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
 #undef MUSTAFAR_LL
             if (prof) { g_prof.onepass++; g_prof.n++; }
             onepass_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, S1 + nchunks, static_cast<h16*>(out), Batch_Size);
+            t_last_choice = fma_engine() | (1 << 4) | ((lp ? 2 : 1) << 8);
             return (int)hipGetLastError();
         }
         const bool pair = fma_engine() != 1 || G != 4;                      // two waves per block unless the matrix-pipe engine runs
@@ -2782,6 +2810,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
 #undef MUSTAFAR_L1
             if (prof) { g_prof.onepass++; g_prof.n++; }
             onepass_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, S1 + nchunks, static_cast<h16*>(out), Batch_Size);
+            t_last_choice = (fma_engine() == 1 && G == 4 ? 1 : 0) | (1 << 4);
             return (int)hipGetLastError();
         }
     }
@@ -2824,6 +2853,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     value_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws, S + nwin_slabs, sc, ld_scores, T, ride_v ? nullptr : vwin, ride_v ? nullptr : vnew,
                                                     window_len, window_capacity, static_cast<h16*>(out), Batch_Size, groups,
                                                     window_len_extra);
+    t_last_choice = (fma_engine() == 1 && G == 4 ? 1 : 0);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -2836,7 +2866,7 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
                               const void* v_new, int window_len, int window_capacity, void* scores, int ld_scores, void* out,
                               void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
                               const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
-                              int heads_per_mask_row)
+                              int heads_per_mask_row, uint32_t flags)
 {
     const mustafar_cache_view kc{const_cast<uint64_t*>(k_bmp), const_cast<void*>(k_nz), const_cast<uint32_t*>(k_idx),
                                  const_cast<uint32_t*>(k_nz_offset), 0, 0, 0};
@@ -2844,7 +2874,7 @@ int mustafar_decode_attention(void* stream, const uint64_t* k_bmp, const void* k
                                  const_cast<uint32_t*>(v_nz_offset), 0, 0, 0};
     return decode_attention(stream, kc, vc, q, k_window, v_window, k_new, v_new, window_len, window_capacity, scores, ld_scores, out,
                             workspace, Split_K, T, Batch_Size, num_key_value_groups, sqrt_d, window_len_extra, attention_mask,
-                            mask_row_stride, heads_per_mask_row);
+                            mask_row_stride, heads_per_mask_row, flags);
 }
 
 int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_cache, const mustafar_cache_view* v_cache,
@@ -2852,13 +2882,13 @@ int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_ca
                                    int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
                                    int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
                                    const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
-                                   int heads_per_mask_row)
+                                   int heads_per_mask_row, uint32_t flags)
 {
     const mustafar_cache_view none{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     if (T > 0 && (!k_cache || !v_cache)) return MUSTAFAR_EINVAL;
     return decode_attention(stream, k_cache ? *k_cache : none, v_cache ? *v_cache : none, q, k_window, v_window, k_new, v_new,
                             window_len, window_capacity, scores, ld_scores, out, workspace, Split_K, T, Batch_Size,
-                            num_key_value_groups, sqrt_d, window_len_extra, attention_mask, mask_row_stride, heads_per_mask_row);
+                            num_key_value_groups, sqrt_d, window_len_extra, attention_mask, mask_row_stride, heads_per_mask_row, flags);
 }
 
 int mustafar_profile_begin(int max_records)
@@ -2930,6 +2960,8 @@ int mustafar_set_onepass(int mode)
 }
 
 int mustafar_get_onepass(void) { return onepass_mode(); }
+
+int mustafar_last_decode_choice(void) { return t_last_choice; }
 
 // Tuning knobs of the experiment scripts (tools/): 0 = lean one-pass form on / off, 1 = blocks per wave of the lean form
 // (0 = automatic), 2 = workgroup target of the pair form (0 = automatic).  Not part of the operator interface.

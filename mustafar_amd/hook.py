@@ -45,6 +45,11 @@ class MustafarConfig:
     arena: bool = False           # api="fused": keep the compressed cache in CompressedArena objects (in-place append)
     arena_extra_tokens: int = 512   # spare token rows of a new arena; its stream regions get arena_headroom x the
     arena_headroom: float = 1.03    # fullest head's bytes per token (cache.py: DEFAULT_EXTRA_TOKENS / DEFAULT_HEADROOM)
+    # api="fused": this instance's FMA engine ("dot2" | "valu" | "mfma"; None = the process default) and launch structure
+    # ("one_pass" | "two_launch"; None = by size).  Carried in every call's `flags` (include/mustafar_hip.h): two instances in
+    # one process run what each of them asks for.
+    engine: Optional[str] = None
+    structure: Optional[str] = None
 
 
 def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:
@@ -256,8 +261,8 @@ class MustafarAttention:
         """Same contract as decode() with api="native"; windows are `Window` objects appended in place.
 
         `attention_mask` is the hook's additive mask [bsz, 1, 1, kv_seq_len] (model :293-301), applied inside the softmax
-        kernel exactly as the model does (fp16 add, clamp at finfo.min).  Under graph replay (`step_counter`) pass a
-        buffer whose rows are at least `compressed_length + window capacity` long: the kernels read the first
+        kernel exactly as the model does (fp16 add, clamp at finfo.min).  Under graph replay (`step_counter`) the rows must
+        be at least `compressed_length + window capacity` long (checked: a shorter mask raises): the kernels read the first
         `kv_seq_len` columns of each row, whatever the step.
 
         `step_counter` (int32 device tensor, optional) is added to the window length inside the kernels, so that a
@@ -286,7 +291,8 @@ class MustafarAttention:
             raise RuntimeError("key/value windows must have the same capacity")
         mask_ptr, mask_stride = None, 0
         if attention_mask is not None:
-            need = C + w_len if step_counter is None else C + 1   # (a replayed graph reads more columns as the window grows)
+            # a replayed graph reads more columns as the window grows: up to the window capacity (the bound ld_scores gets too)
+            need = C + w_len if step_counter is None else C + k_w.cap
             if attention_mask.dim() != 4 or attention_mask.shape[:3] != (bsz, 1, q_len) or attention_mask.shape[3] < need or \
                     (step_counter is None and attention_mask.shape[3] != kv_seq_len):
                 raise ValueError(f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {tuple(attention_mask.size())}")   # :294-297
@@ -299,7 +305,8 @@ class MustafarAttention:
         use_arena = isinstance(k_c, CompressedArena)
         tail = (q.data_ptr(), k_w.buf.data_ptr(), v_w.buf.data_ptr(), kn.data_ptr(), vn.data_ptr(), w_len, k_w.cap,
                 scores.data_ptr(), ld, out.data_ptr(), ws.data_ptr(), split, C, BH, groups, math.sqrt(D),
-                step_counter.data_ptr() if step_counter is not None else None, mask_ptr, mask_stride, self.num_heads)
+                step_counter.data_ptr() if step_counter is not None else None, mask_ptr, mask_stride, self.num_heads,
+                _lib.ENGINE_FLAGS[cfg.engine] | _lib.STRUCTURE_FLAGS[cfg.structure])
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             if use_arena:

@@ -141,3 +141,45 @@ def test_masked_decode_under_graph_replay(structure):
         g.replay()
         want = _dense_masked(qn, K_all, V_all, 256, 0.7, 0.7, hq // hkv, mask[..., :L0 + step + 1])
         torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("structure", [0, 1], indirect=True)
+def test_replayed_mask_must_cover_the_window_capacity(structure):
+    """Under graph replay the kernels read mask columns up to compressed_length + window CAPACITY as the window grows: a mask of
+    exactly that length is accepted and right on every replay up to a full window, a shorter one is refused on the host
+    (before round 3 only `compressed_length + 1` columns were required and later replays read past the row)."""
+    from mustafar_amd import _lib
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    torch.manual_seed(21)
+    bsz, hq, hkv, D, L0 = 2, 8, 2, 128, 300
+    attn = MustafarAttention(MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, api="fused", arena=True))
+    K_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    V_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    past = attn.to_fused(attn.build_cache(K_all.clone(), V_all.clone()))
+    cap = past[1].cap
+    q, kn, vn = (torch.zeros(bsz, h, 1, D, device=DEV, dtype=torch.float16) for h in (hq, hkv, hkv))
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    short = torch.zeros((bsz, 1, 1, 256 + cap - 1), dtype=torch.float16, device=DEV)
+    with pytest.raises(ValueError, match="Attention mask should be of size"):
+        attn.decode_fused(q, kn, vn, past, step_counter=counter, attention_mask=short)
+    mask = torch.zeros((bsz, 1, 1, 256 + cap), dtype=torch.float16, device=DEV)     # exactly compressed_length + capacity
+    mask[0, :, :, 10:60] = NEG
+    mask[1, :, :, 256 + 50:256 + 70] = NEG                                              # columns the window only reaches later
+    lib = _lib.load()
+    warm = (past[0], past[1].clone(), past[2], past[3].clone(), past[4], past[5])
+    attn.decode_fused(q, kn, vn, warm, attention_mask=mask[..., :L0 + 1].contiguous())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out, _ = attn.decode_fused(q, kn, vn, past, step_counter=counter, attention_mask=mask)
+        _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream().cuda_stream, counter.data_ptr(), 1), "counter")
+    steps = cap - (L0 - 256)            # until the window is full: the last replay reads the mask's last column
+    for step in range(steps):
+        qn, k1, v1 = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+        q.copy_(qn); kn.copy_(k1); vn.copy_(v1)
+        K_all, V_all = torch.cat([K_all, k1], 2), torch.cat([V_all, v1], 2)
+        g.replay()
+        if step % 7 == 0 or step >= steps - 2:
+            want = _dense_masked(qn, K_all, V_all, 256, 0.7, 0.7, hq // hkv, mask[..., :L0 + step + 1])
+            torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3)
+    assert K_all.shape[2] == 256 + cap

@@ -31,7 +31,7 @@ def fma_engine(request):
     L = _lib.load()
     assert L.mustafar_set_fma_engine(1 if request.param == "mfma" else 0) == 0
     yield request.param
-    L.mustafar_set_fma_engine(0)
+    L.mustafar_set_fma_engine(2)   # the process default
 
 
 def _t(a, dtype=None):

@@ -35,7 +35,7 @@ def test_cabi_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for s in syms:
         assert hasattr(raw, s), f"{s} not exported"
-    assert L.mustafar_abi_version() >= 101
+    assert L.mustafar_abi_version() >= 102
     # pure host helpers (no device access)
     s = L.mustafar_value_pick_split_k(128, 1, 7936, 256, 4)
     assert 1 <= s <= 31
@@ -50,13 +50,16 @@ def test_cache_view_strides_are_validated_without_a_gpu():
     L = _lib.load()
     one = 8   # never dereferenced: validation fails first
     T = 128
-    ok_args = (one, one, one, None, None, 1, 64, one, T + 64, one, one, 1, T, 4, 1, ctypes.c_float(11.3), None, None, 0, 0)
+    ok_args = (one, one, one, None, None, 1, 64, one, T + 64, one, one, 1, T, 4, 1, ctypes.c_float(11.3), None, None, 0, 0, 0)
     short = _lib.CacheView(one, one, one, one, 2 * T - 1, 0)
     good = _lib.CacheView(one, one, one, one, 2 * T, 2 * T + 1)
     assert L.mustafar_decode_attention_view(None, ctypes.byref(short), ctypes.byref(good), *ok_args) == 1
     assert L.mustafar_decode_attention_view(None, ctypes.byref(good), None, *ok_args) == 1
     short_idx = _lib.CacheView(one, one, one, one, 0, 2 * T)
     assert L.mustafar_decode_attention_view(None, ctypes.byref(good), ctypes.byref(short_idx), *ok_args) == 1
+    # undefined bits of `flags` (engine field 4..7, structure field 3, anything above bit 5) are rejected before any launch
+    for bad in (4, 7, 3 << 4, 1 << 6, 1 << 31):
+        assert L.mustafar_decode_attention_view(None, ctypes.byref(good), ctypes.byref(good), *(ok_args[:-1] + (bad,))) == 1
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
