@@ -188,11 +188,16 @@ int mustafar_counter_add(void* stream, int32_t* counter, int delta);
  *   k_x / v_x       fp16 rows of 128; head h starts `head_stride` elements after head h - 1 (a window buffer: capacity * 128)
  *   *_head_total    i64 [B'] out: every head's new stream length in halfs (read it whenever convenient, e.g. through an
  *                   asynchronous copy: the next append needs it only to decide about room)
- *   *_region_halfs  room of a head's stream region (0 = unchecked); overflow_flag (device int, may be NULL): set when a head
- *                   outgrows its region (bit 0) -- the blocks that would cross the end of the region then write no stream
- *                   bytes (bitmaps / offsets of the new tokens are there): re-house and repeat; bit 1: a block gave up
- *                   waiting for the lengths in front of it (never seen; the poll is bounded so that every wave exits).
- *                   Callers keep room for one worst-case append (t * 128 halfs).
+ *   *_region_halfs  room of a head's stream region (0 = unchecked); overflow_flag (device int, REQUIRED; the caller zeroes it):
+ *                   bit 0 = a head outgrew its region -- the blocks that would cross the end of the region then write no stream
+ *                   bytes (the bitmaps / offsets of the new tokens and *_head_total, the length the head NEEDS, are written):
+ *                   re-house at that length and repeat the call with the same old_tokens (it is idempotent);
+ *                   bit 1 = a block gave up waiting for the lengths of the blocks in front of it and wrote nothing (the poll is
+ *                   bounded so that every wave exits; it relies on workgroups being dispatched in order of their linear id, which
+ *                   holds on gfx950; never seen): a hard error, the appended tokens are incomplete -- MUSTAFAR_COMPRESS=twopass in
+ *                   the environment selects the three-launch form that has no such wait.
+ *                   A caller that cannot read the flag right behind the launch (graph capture) keeps room for one worst-case
+ *                   append (t * 128 halfs): bit 0 is then impossible.
  *   scratch         mustafar_compress_scratch_bytes(B', t) bytes
  */
 int64_t mustafar_compress_scratch_bytes(int Bp, int t);

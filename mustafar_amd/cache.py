@@ -3,16 +3,31 @@
 The reference keeps the compressed cache as `[bitmaps, idxs, nzs(list per kv-head), nz_offset]` and, on every 256-token
 trigger, rebuilds all of it: `torch.cat` of the bitmaps and offsets of every head, one `torch.cat` per head for the
 streams, a Python list of device scalars for the offsets (models/llama_mustafar_kernel.py:339-390).  `CompressedArena`
-holds the same four arrays with spare capacity -- a head's bitmap / offset rows are `cap_tokens` long, every head's
-stream has its own region of `nz_cap` halfs -- so an append is two kernel passes over the NEW tokens only
-(`mustafar_cache_append_*`) plus one B'-element device->host read that checks the stream regions still fit.
+holds the same four arrays with a little spare capacity -- a head's bitmap / offset rows are `cap_tokens` long, every head's
+stream has its own region of `nz_cap` halfs -- so an append writes the NEW tokens only.
 
 The format is unchanged (bit order, padding to 8, offsets in half2 units, `nz_offset` in uint4 units): the SpMV kernels
 read an arena through `mustafar_cache_view` (head strides), and `to_reference()` returns the reference's contiguous list.
+
+Sizing (round 3).  Whatever is allocated beyond the bytes in use counts against the metric's second half (peak KV bytes), so
+an arena is housed at `(1 + slack)` x what it holds (`DEFAULT_SLACK` = 5 %: token rows and stream regions alike) and nothing
+is reserved for a worst-case append any more:
+  * an append first makes room for what it EXPECTS to add (the head's measured halfs per token x 1.04) -- re-housing the arena
+    at `(1 + slack)` x the new size when that does not fit (at a 768-token cache that is every trigger, a copy of a few MB,
+    what the reference does with a dozen `torch.cat`s; at 8 k tokens every other trigger);
+  * the launch reports every head's true new length and refuses to write past a region (device flag, bit 0); the host reads
+    the flag and the lengths right behind the launch (one small device->host read per trigger, as `append()` always had) and, if
+    a head did outgrow its region -- rows full of ties keep more than the expected count, model :107 -- re-houses at the
+    measured size and repeats the launch (the raw rows are still in place: the window slides afterwards);
+  * only when a region already has room for a worst-case append (t x 128 halfs: nothing can overflow) does the call stay
+    asynchronous, as in round 2: lengths and flag then travel through pinned memory and are looked at on the next use.
+Bit 1 of the flag (a block of the one-pass compression gave up waiting for the lengths in front of it: it relies on lower
+workgroup ids being dispatched first) is a hard error with its own exception; it is never answered by a retry.
 """
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 from typing import List, Optional
 
@@ -20,20 +35,32 @@ import torch
 
 from . import _lib
 
+DEFAULT_SLACK = 0.05
 
-# Spare capacity of a new arena: rows for two more 256-token appends, stream regions 3 % over the fullest head's measured
-# bytes per token (the heads of one layer differ by < 1 % on i.i.d. data; an append that does not fit re-houses the cache).
-# Round 1 reserved t + 1024 tokens x 1.08 = 22 % over the bytes in use at c3; this is ~10 %.
-DEFAULT_EXTRA_TOKENS = 512
-DEFAULT_HEADROOM = 1.03
+
+class ArenaAppendTimeout(RuntimeError):
+    """The one-pass compression launch gave up waiting for a predecessor block's length (device flag bit 1).  The appended
+    tokens are incomplete; MUSTAFAR_COMPRESS=twopass selects the form without that dependence."""
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _cap_rows(tokens: int, slack: float) -> int:
+    return _round_up(int(math.ceil(tokens * (1.0 + slack))), 64)
+
+
+def _cap_nz(halfs: int, slack: float) -> int:
+    return _round_up(int(halfs * (1.0 + slack)) + 256, 8)
 
 
 class CompressedArena:
     TILES_PER_TOKEN = 2   # head_dim 128 / 64
 
-    def __init__(self, heads: int, which: str, device, cap_tokens: int, nz_cap: int):
+    def __init__(self, heads: int, which: str, device, cap_tokens: int, nz_cap: int, slack: float = DEFAULT_SLACK):
         assert which in ("key", "value") and cap_tokens % 64 == 0 and nz_cap % 8 == 0
-        self.heads, self.which, self.device = heads, which, device
+        self.heads, self.which, self.device, self.slack = heads, which, device, slack
         self.tokens = 0
         self._alloc(cap_tokens, nz_cap)
 
@@ -48,9 +75,10 @@ class CompressedArena:
         self.nz_offset = (torch.arange(self.heads, dtype=torch.int64, device=self.device) * (nz_cap // 8)).to(torch.int32)
         self._totals = torch.empty(self.heads, dtype=torch.int64, device=self.device)
         self._used = torch.zeros(self.heads, dtype=torch.int64)   # host copy of every head's stream length (halfs)
-        self._host_totals = torch.zeros(self.heads, dtype=torch.int64).pin_memory() if self.device.type == "cuda" else None
-        self._pending = None                                        # event behind an asynchronous copy of _totals into _host_totals
+        self._host_totals = None                                    # pinned landing area of an asynchronous append's lengths
+        self._pending = None                                        # (event, tokens appended) behind an asynchronous append
         self._overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._host_flag = None
         self._view = _lib.CacheView(self.bmp.data_ptr(), self.nz.data_ptr(), self.idx.data_ptr(), self.nz_offset.data_ptr(),
                                     tiles, tiles + 1,
                                     nz_cap // 8 if (self.heads * (nz_cap // 8) < 2 ** 32 and os.environ.get("MUSTAFAR_NZ_STRIDE", "1") != "0") else 0)
@@ -59,24 +87,40 @@ class CompressedArena:
     def view(self) -> "_lib.CacheView":
         return self._view
 
+    def _settle(self, wait: bool = True) -> None:
+        """Take in the lengths and the flag of an asynchronous append (see the module docstring).  wait=False: only if the copy
+        has landed already (the decode path calls this before every read of the arena: no host stall, and a failed append
+        is reported before the cache is used again rather than 256 steps later)."""
+        if self._pending is None:
+            return
+        ev, t = self._pending
+        if not wait and not ev.query():
+            return
+        ev.synchronize()
+        self._pending = None
+        flag = int(self._host_flag[0])
+        if flag:
+            self.tokens -= t                     # the append did not complete: the cache is what it was before it
+            self._overflow.zero_()
+            if flag & 2:
+                raise ArenaAppendTimeout("CompressedArena: a block of the one-pass compression timed out waiting for the stream lengths in front "
+                                         "of it; the 256 tokens of this trigger were not appended (MUSTAFAR_COMPRESS=twopass avoids the wait)")
+            raise RuntimeError("CompressedArena: a head outgrew a stream region that had room for a worst-case append: this is a bug")
+        self._used = self._host_totals.clone()
+
     @property
     def used(self) -> torch.Tensor:
-        """Exact stream length of every head in halfs (host tensor).  After an asynchronous append (append_window_pair)
-        the figures arrive through a pinned-memory copy; reading them here waits for that copy if it is still in flight
-        (it was enqueued a trigger period -- 256 decode steps -- ago in the decode loop)."""
-        if self._pending is not None:
-            self._pending.synchronize()
-            self._pending = None
-            self._used = self._host_totals.clone()
-            if int(self._overflow.item()):
-                raise RuntimeError("CompressedArena: a head outgrew its stream region during an asynchronous append "
-                                   "(room for one worst-case append is reserved beforehand: this is a bug)")
+        """Exact stream length of every head in halfs (host tensor); waits for an asynchronous append still in flight."""
+        self._settle()
         return self._used
 
     @used.setter
     def used(self, value: torch.Tensor):
         self._pending = None
         self._used = value
+
+    def poll(self) -> None:
+        self._settle(wait=False)
 
     def view_ptr(self):
         return ctypes.byref(self._view)
@@ -88,11 +132,8 @@ class CompressedArena:
     def bytes_reserved(self) -> int:
         return sum(x.numel() * x.element_size() for x in (self.bmp, self.idx, self.nz, self.nz_offset))
 
-    def _grow(self, cap_tokens: int, nz_cap: int):
-        """Re-house the cache with larger rows / regions (amortised: capacities grow geometrically)."""
-        self._rehouse(max(cap_tokens, self.cap_tokens), max(nz_cap, self.nz_cap))
-
     def _rehouse(self, cap_tokens: int, nz_cap: int):
+        """Move the cache into rows of `cap_tokens` tokens and stream regions of `nz_cap` halfs (never below what it holds)."""
         old = (self.bmp, self.idx, self.nz, self.used.clone(), self.tokens)   # (resolves a pending asynchronous append)
         assert cap_tokens >= self.tokens and nz_cap >= (int(self.used.max()) if self.tokens else 0)
         self._alloc(cap_tokens, nz_cap)
@@ -104,7 +145,27 @@ class CompressedArena:
         self.nz[:, :m] = o_nz[:, :m]
         self.used, self.tokens = used, tokens
 
-    # ---- append (model :339-390) -----------------------------------------------------------------------------
+    def _make_room(self, t: int, need_halfs: int) -> None:
+        """Rows for t more tokens and stream regions of at least need_halfs, re-housed at (1 + slack) x the new size if either is short."""
+        rows, nz = self.cap_tokens, self.nz_cap
+        if self.tokens + t > rows:
+            rows = _cap_rows(self.tokens + t, self.slack)
+        if need_halfs > nz:
+            nz = _cap_nz(need_halfs, self.slack)
+        if rows != self.cap_tokens or nz != self.nz_cap:
+            self._rehouse(rows, nz)
+
+    def _expected_append(self, t: int, kth: int) -> int:
+        """Halfs a t-token append is expected to add to the fullest head: its measured halfs per token (the kept count + padding
+        to 8 per tile; + 4 %), or the count the prune rule keeps without ties when nothing has been measured yet."""
+        used = int(self.used.max()) if self.tokens else 0
+        if self.tokens >= 64 and used > 0:
+            per_token = used / float(self.tokens)
+        else:
+            per_token = float(136 if kth <= 0 else 128 - kth + 1 + 8)
+        return int(t * per_token * 1.04) + 256
+
+    # ---- append of PRUNED tokens, two passes (model :339-390) --------------------------------------------------
     def append(self, x: torch.Tensor) -> None:
         """x: pruned fp16 [B', t, 128], t % 64 == 0 -> appended behind the tokens in use."""
         if x.dim() != 3 or x.shape[0] != self.heads or x.shape[2] != 128 or x.shape[1] % 64 or x.dtype != torch.float16:
@@ -113,9 +174,7 @@ class CompressedArena:
             x = x.contiguous()
         t = x.shape[1]
         L = _lib.load()
-        if self.tokens + t > self.cap_tokens:   # rows full: a quarter more (at least 1024 tokens), the stream regions in proportion
-            cap = _round_up(max(self.cap_tokens + max(1024, self.cap_tokens // 4), self.tokens + t), 256)
-            self._grow(cap, _round_up(int(self.nz_cap * (cap / float(self.cap_tokens))) + 8, 8))
+        self._make_room(t, 0)
         st = torch.cuda.current_stream(self.device).cuda_stream
         key = self.which == "key"
         with torch.cuda.device(self.device):
@@ -125,24 +184,36 @@ class CompressedArena:
             totals = self._totals.cpu()                  # the one host read of an append (B' values)
             need = int(totals.max())
             if need > self.nz_cap:                       # the new tiles do not fit behind some head's stream: re-house, redo pass 1
-                per_token = need / float(self.tokens + t)
-                self._grow(self.cap_tokens, _round_up(int(per_token * self.cap_tokens * 1.05) + 1024, 8))
+                self._make_room(t, need)
                 _lib.check(f(st, x.data_ptr(), self.heads, t, 128, self.view_ptr(), self.tokens, self._totals.data_ptr()),
                            "mustafar_cache_append_bitmap")
             g = L.mustafar_cache_append_pack_key if key else L.mustafar_cache_append_pack_value
             _lib.check(g(st, x.data_ptr(), self.heads, t, 128, self.view_ptr(), self.tokens), "mustafar_cache_append_pack")
         self.used, self.tokens = totals, self.tokens + t
 
-    # ---- fused trigger: prune + compress + append of the RAW window rows of K and V, no host read (model :324-398) ---------
+    # ---- fused trigger: prune + compress + append of the RAW window rows of K and V (model :324-398) -----------------------
+    @staticmethod
+    def _launch_pair(k_arena, v_arena, k_rows, v_rows, t, kth_k, kth_v):
+        L = _lib.load()
+        dev = k_arena.device
+        scratch = k_arena._scratch_for(t)
+        flag = k_arena._overflow
+        st = torch.cuda.current_stream(dev).cuda_stream
+        err = L.mustafar_cache_append_kv(st, k_rows.data_ptr(), v_rows.data_ptr(), k_rows.shape[2] * 128, k_arena.heads, t, 128, kth_k, kth_v,
+                                         k_arena.view_ptr(), v_arena.view_ptr(), k_arena.tokens, k_arena._totals.data_ptr(),
+                                         v_arena._totals.data_ptr(), k_arena.nz_cap, v_arena.nz_cap, flag.data_ptr(), scratch.data_ptr())
+        _lib.check(err, "mustafar_cache_append_kv")
+        return flag
+
     @staticmethod
     def append_window_pair(k_arena: "CompressedArena", v_arena: "CompressedArena", k_rows: torch.Tensor, v_rows: torch.Tensor,
-                           t: int, kth_k: int, kth_v: int) -> None:
+                           t: int, kth_k: int, kth_v: int, expect: bool = True) -> None:
         """k_rows / v_rows: fp16 [B, Hkv, >= t, 128] buffers (a window: rows [0, t) of every head are compressed; the row
         stride between heads is the buffer's) holding RAW (unpruned) tokens; kth = max(1, int(sparsity * 128)) (model :97),
-        0 for rows that are already pruned.  One launch for both sides (mustafar_cache_append_kv), nothing allocated
-        on the device side of the call and nothing read back: room for one worst-case append (t * 128 halfs per head) is
-        secured BEFORE the launches from the exact stream lengths of the previous append, which travel to the host through
-        an asynchronous pinned-memory copy enqueued right behind it."""
+        0 for rows that are already pruned.  One launch for both sides (mustafar_cache_append_kv), then -- unless both arenas had
+        room for a worst-case append -- one read of the flag and the lengths, and a repeat at the measured size if a head
+        outgrew its region (module docstring).  The rows must stay in place until this returns.  expect=False: the caller has
+        just sized the regions itself (from_raw_pair): no room is made beforehand, an overflow is answered by the measured size."""
         heads = k_arena.heads
         if v_arena.heads != heads or k_arena.tokens != v_arena.tokens or t % 64 or t <= 0:
             raise RuntimeError("append_window_pair: K and V arenas must describe the same heads and tokens; t % 64 == 0")
@@ -152,32 +223,44 @@ class CompressedArena:
                 raise RuntimeError("append_window_pair expects contiguous fp16 [B, Hkv, rows >= t, 128] buffers")
         if k_rows.shape[2] != v_rows.shape[2]:
             raise RuntimeError("append_window_pair: K and V buffers must have the same number of rows per head")
-        L = _lib.load()
-        for a in (k_arena, v_arena):
-            need_rows = a.tokens + t > a.cap_tokens
-            need_room = int(a.used.max()) + t * 128 > a.nz_cap          # (a.used waits for the previous append's figures if need be)
-            if need_rows or need_room:
-                cap = a.cap_tokens
-                if need_rows:
-                    cap = _round_up(max(cap + max(1024, cap // 4), a.tokens + t), 256)
-                per_token = float(a.used.max()) / max(a.tokens, 1) if a.tokens else 72.0
-                nz_cap = max(a.nz_cap, _round_up(int(per_token * cap * DEFAULT_HEADROOM) + t * 128 + 1024, 8))
-                a._rehouse(cap, nz_cap)
         dev = k_arena.device
-        scratch = k_arena._scratch_for(t)
+        for a, kth in ((k_arena, kth_k), (v_arena, kth_v)):
+            used = int(a.used.max()) if a.tokens else 0            # (a.used waits for an asynchronous append still in flight)
+            a._make_room(t, used + (a._expected_append(t, kth) if expect else 0))
+        worst = t * 128
+        safe = all(a.nz_cap - (int(a.used.max()) if a.tokens else 0) >= worst for a in (k_arena, v_arena))
+        v_arena._overflow = k_arena._overflow                       # one flag per pair and call
         with torch.cuda.device(dev):
-            st = torch.cuda.current_stream(dev).cuda_stream
-            err = L.mustafar_cache_append_kv(st, k_rows.data_ptr(), v_rows.data_ptr(), k_rows.shape[2] * 128, heads, t, 128, kth_k, kth_v,
-                                             k_arena.view_ptr(), v_arena.view_ptr(), k_arena.tokens, k_arena._totals.data_ptr(),
-                                             v_arena._totals.data_ptr(), k_arena.nz_cap, v_arena.nz_cap, k_arena._overflow.data_ptr(),
-                                             scratch.data_ptr())
-            _lib.check(err, "mustafar_cache_append_kv")
-            for a in (k_arena, v_arena):
-                a._host_totals.copy_(a._totals, non_blocking=True)
-                a._pending = torch.cuda.Event()
-                a._pending.record(torch.cuda.current_stream(dev))
-                a.tokens += t
-        v_arena._overflow = k_arena._overflow   # one flag per pair and call (either side's `used` reports it)
+            if safe:   # nothing can overflow: stay asynchronous, lengths and flag through pinned memory (looked at on the next use)
+                CompressedArena._launch_pair(k_arena, v_arena, k_rows, v_rows, t, kth_k, kth_v)
+                ev = torch.cuda.Event()
+                for a in (k_arena, v_arena):
+                    if a._host_totals is None:
+                        a._host_totals = torch.zeros(a.heads, dtype=torch.int64).pin_memory()
+                        a._host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    a._host_totals.copy_(a._totals, non_blocking=True)
+                    a._host_flag.copy_(a._overflow, non_blocking=True)
+                ev.record(torch.cuda.current_stream(dev))
+                for a in (k_arena, v_arena):
+                    a._pending = (ev, t)
+                    a.tokens += t
+                return
+            for attempt in range(2):
+                flag = int(CompressedArena._launch_pair(k_arena, v_arena, k_rows, v_rows, t, kth_k, kth_v).item())   # (waits for the launch)
+                totals = (k_arena._totals.cpu(), v_arena._totals.cpu())
+                if flag:
+                    k_arena._overflow.zero_()
+                if flag & 2:
+                    raise ArenaAppendTimeout("CompressedArena: a block of the one-pass compression timed out waiting for the stream lengths in "
+                                             "front of it; nothing was appended (MUSTAFAR_COMPRESS=twopass avoids the wait)")
+                if not flag:
+                    for a, tot in zip((k_arena, v_arena), totals):
+                        a.used, a.tokens = tot, a.tokens + t
+                    return
+                if attempt:
+                    raise RuntimeError("CompressedArena: a head outgrew a stream region sized from the launch's own report: this is a bug")
+                for a, tot in zip((k_arena, v_arena), totals):     # bit 0: the lengths the launch reported are exact: house them and repeat
+                    a._make_room(t, int(tot.max()))
 
     def _scratch_for(self, t: int) -> torch.Tensor:
         n = int(_lib.load().mustafar_compress_scratch_bytes(self.heads, t))
@@ -188,62 +271,51 @@ class CompressedArena:
 
     @classmethod
     def from_raw_pair(cls, k_rows: torch.Tensor, v_rows: torch.Tensor, t: int, kth_k: int, kth_v: int, cap_tokens: Optional[int] = None,
-                      headroom: float = DEFAULT_HEADROOM):
+                      slack: float = DEFAULT_SLACK):
         """Prefill (model :416-437): prune + compress the first t tokens of raw K / V [B, Hkv, L, 128] into two new arenas,
-        one read of the dense block per side and no pruned copy.  The stream regions start from an estimate (kept values
-        per token + padding, + 12 %) and are re-housed at the measured size."""
+        one read of the dense block per side and no pruned copy.  Rows: (1 + slack) x t (at least `cap_tokens`); stream regions:
+        from the count the prune rule keeps without ties (+ 8 halfs of padding per token, the average of two tiles rounded up to
+        eight), grown to the measured size and the launch repeated if a head needs more, and shrunk if far too large."""
         heads = k_rows.shape[0] * k_rows.shape[1]
-        cap = _round_up(cap_tokens if cap_tokens else t + DEFAULT_EXTRA_TOKENS, 256)
+        rows = max(_cap_rows(t, slack), _round_up(cap_tokens or 0, 64))
 
-        def region(kth: int, worst: bool) -> int:   # halfs per head
-            kept = 128 if (worst or kth == 0) else 128 - kth + 1       # without ties; ties keep more (model :107)
-            return _round_up(int(t * (kept + 9) * (1.0 if worst else 1.12)) + 2048, 8)
+        def region(kth: int) -> int:   # halfs per head
+            kept = 128 if kth <= 0 else 128 - kth + 1
+            return _cap_nz(int(t * min(kept + 8, 136) * 1.01) + 512, slack)
 
-        for worst in (False, True):
-            k = cls(heads, "key", k_rows.device, _round_up(t, 64), region(kth_k, worst))
-            v = cls(heads, "value", v_rows.device, _round_up(t, 64), region(kth_v, worst))
-            k._used = torch.full((heads,), -t * 128, dtype=torch.int64)   # (no room check: an overflow is handled right here)
-            v._used = k._used.clone()
-            cls.append_window_pair(k, v, k_rows, v_rows, t, kth_k, kth_v)
-            try:
-                k.used, v.used                       # wait for the stream lengths; raises if a head outgrew its region
-                break
-            except RuntimeError:
-                if worst:
-                    raise
+        k = cls(heads, "key", k_rows.device, rows, region(kth_k), slack)
+        v = cls(heads, "value", v_rows.device, rows, region(kth_v), slack)
+        cls.append_window_pair(k, v, k_rows, v_rows, t, kth_k, kth_v, expect=False)
         for a in (k, v):
-            per_token = float(a.used.max()) / max(t, 1)
-            a._rehouse(cap, _round_up(int(per_token * cap * headroom) + 1024, 8))
+            tight = _cap_nz(int(a.used.max()), slack)
+            if a.nz_cap > tight + tight // 32:          # an estimate above the data (rows with many zeros): give the room back
+                a._rehouse(a.cap_tokens, tight)
         return k, v
 
     # ---- conversion ------------------------------------------------------------------------------------------
     @classmethod
-    def from_pruned(cls, x: torch.Tensor, which: str, cap_tokens: Optional[int] = None, headroom: float = DEFAULT_HEADROOM) -> "CompressedArena":
-        """Compress x [B', t, 128] (already pruned) into a new arena sized for `cap_tokens` (default: t + DEFAULT_EXTRA_TOKENS)
-        with stream regions of `headroom` x the measured halfs per token."""
+    def from_pruned(cls, x: torch.Tensor, which: str, cap_tokens: Optional[int] = None, slack: float = DEFAULT_SLACK) -> "CompressedArena":
+        """Compress x [B', t, 128] (already pruned) into a new arena: rows (1 + slack) x t (at least `cap_tokens`), stream regions
+        (1 + slack) x the measured halfs."""
         heads, t, _ = x.shape
-        cap = _round_up(cap_tokens if cap_tokens else t + DEFAULT_EXTRA_TOKENS, 256)
-        # first pass into rows of exactly t tokens and a generous guess for the streams (dense would be 128 halfs per
-        # token), then re-house at the measured size: the transient is freed, the resident footprint is tight
-        a = cls(heads, which, x.device, _round_up(t, 64), _round_up(t * 72 + 1024, 8))
+        rows = max(_cap_rows(t, slack), _round_up(cap_tokens or 0, 64))
+        a = cls(heads, which, x.device, rows, _round_up(t * 56 + 1024, 8), slack)   # (append() re-houses at the measured size if short)
         a.append(x)
-        per_token = float(a.used.max()) / max(t, 1)
-        nz_cap = _round_up(int(per_token * cap * headroom) + 1024, 8)
-        if cap != a.cap_tokens or nz_cap != a.nz_cap:
-            a._rehouse(cap, nz_cap)
+        tight = _cap_nz(int(a.used.max()), slack)
+        if a.nz_cap > tight + tight // 32:
+            a._rehouse(a.cap_tokens, tight)
         return a
 
     @classmethod
     def from_reference(cls, compressed: list, which: str, tokens: int, cap_tokens: Optional[int] = None,
-                       headroom: float = DEFAULT_HEADROOM) -> "CompressedArena":
+                       slack: float = DEFAULT_SLACK) -> "CompressedArena":
         """Re-house a reference-layout cache `[bitmaps, idxs, nzs, nz_offset]` holding `tokens` tokens per head."""
         bmp, idx, nzs, _ = compressed
         heads = len(nzs)
         t = tokens * cls.TILES_PER_TOKEN
         used = torch.tensor([n.numel() for n in nzs], dtype=torch.int64)
-        cap = _round_up(cap_tokens if cap_tokens else tokens + DEFAULT_EXTRA_TOKENS, 256)
-        per_token = float(used.max()) / max(tokens, 1)
-        a = cls(heads, which, bmp.device, cap, _round_up(int(per_token * cap * headroom) + 1024, 8))
+        rows = max(_cap_rows(tokens, slack), _round_up(cap_tokens or 0, 64))
+        a = cls(heads, which, bmp.device, rows, _cap_nz(int(used.max()), slack), slack)
         a.bmp[:, :t] = bmp.view(heads, t)
         a.idx[:, :t + 1] = idx.view(heads, t + 1)
         for h in range(heads):
@@ -259,7 +331,3 @@ class CompressedArena:
         idx = self.idx[:, :t + 1].contiguous()
         per_head: List[torch.Tensor] = [self.nz[h, :int(self.used[h])].clone() for h in range(self.heads)]
         return [bmp, idx, FlatStreams(per_head), nz_offset_from_idxs(idx, self.heads)]
-
-
-def _round_up(x: int, m: int) -> int:
-    return (x + m - 1) // m * m

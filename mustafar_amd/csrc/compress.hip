@@ -761,6 +761,9 @@ int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int
         {static_cast<const uint16_t*>(v_x), head_stride, reinterpret_cast<int64_t*>(v_dst->bmp), reinterpret_cast<int32_t*>(v_dst->idx), nullptr,
          v_head_total, nullptr, v_dst->nz_offset, static_cast<uint16_t*>(v_dst->nz), vr, v_region_halfs, kth_v, 0}};
     if (one_pass_compress()) {
+        // the one-pass form can fail at run time (a head outgrowing its region; a block giving up on its predecessors' lengths):
+        // without the flag either would pass silently, so the flag is required here
+        if (!overflow_flag) return MUSTAFAR_EINVAL;
         const int ntb = t / 64;
         const int err = (int)hipMemsetAsync(scratch, 0, 2 * (size_t)Bp * ntb * sizeof(uint64_t), st);   // the length words: not yet valid
         if (err) return err;

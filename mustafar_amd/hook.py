@@ -43,8 +43,7 @@ class MustafarConfig:
     group_size: int = 32          # carried by the reference config, unused on the kernel path
     api: str = "native"           # "reference" | "native" | "fused"
     arena: bool = False           # api="fused": keep the compressed cache in CompressedArena objects (in-place append)
-    arena_extra_tokens: int = 512   # spare token rows of a new arena; its stream regions get arena_headroom x the
-    arena_headroom: float = 1.03    # fullest head's bytes per token (cache.py: DEFAULT_EXTRA_TOKENS / DEFAULT_HEADROOM)
+    arena_slack: float = 0.05       # an arena is housed at (1 + arena_slack) x the rows / stream bytes it holds (cache.py: DEFAULT_SLACK)
     # api="fused": this instance's FMA engine ("dot2" | "valu" | "mfma"; None = the process default) and launch structure
     # ("one_pass" | "two_launch"; None = by size).  Carried in every call's `flags` (include/mustafar_hip.h): two instances in
     # one process run what each of them asks for.
@@ -126,7 +125,7 @@ class Window:
 
     def reserve(self, n: int):
         if n > self.cap:
-            nb = torch.empty((self.buf.shape[0], self.buf.shape[1], n + 64, self.buf.shape[3]), dtype=self.buf.dtype,
+            nb = torch.empty((self.buf.shape[0], self.buf.shape[1], n, self.buf.shape[3]), dtype=self.buf.dtype,
                              device=self.buf.device)
             nb[:, :, :self.len] = self.buf[:, :, :self.len]
             self.buf = nb
@@ -188,20 +187,24 @@ class MustafarAttention:
         total_batch_kv = bsz * self.num_key_value_heads
         # :416 computes ((L - R)//256)*256, which is -256 for L < R; clamp at 0.
         compressed_length = max(0, ((kv_seq_len - self.cfg.residual_length) // 256) * 256)
-        if compressed_length != 0 and self.cfg.arena and self.cfg.api == "fused" and key_states.is_contiguous() and value_states.is_contiguous():
-            # straight from the raw K / V into appendable storage: prune thresholds in registers, no pruned copy (:419-434)
+        if compressed_length != 0 and self.cfg.arena and self.cfg.api == "fused":
+            # straight from the raw K / V into appendable storage: prune thresholds in registers, no pruned copy (:419-434).
+            # In the model K and V arrive as transpose(1, 2) views of [B, L, H, D] projections (model :224-226; RoPE keeps the
+            # strides): the kernel reads rows of 128 contiguous halfs per head, so such views are made contiguous first.
+            ks = key_states if key_states.is_contiguous() else key_states.contiguous()
+            vs = value_states if value_states.is_contiguous() else value_states.contiguous()
             k_compressed, v_compressed = CompressedArena.from_raw_pair(
-                key_states, value_states, compressed_length, compression.kth_from_sparsity(self.cfg.k_sparsity, D),
-                compression.kth_from_sparsity(self.cfg.v_sparsity, D), compressed_length + self.cfg.arena_extra_tokens, self.cfg.arena_headroom)
+                ks, vs, compressed_length, compression.kth_from_sparsity(self.cfg.k_sparsity, D),
+                compression.kth_from_sparsity(self.cfg.v_sparsity, D), None, self.cfg.arena_slack)
+            del ks, vs
             k_local_window = key_states[:, :, compressed_length:, :].clone().contiguous()             # :427
             v_local_window = value_states[:, :, compressed_length:, :].clone().contiguous()           # :435
         elif compressed_length != 0:
             k_pruned = self.dh_prune_key(key_states[:, :, :compressed_length, :])                     # :419
             v_pruned = self.dh_prune_value(value_states[:, :, :compressed_length, :])                 # :420
-            if self.cfg.arena and self.cfg.api == "fused":   # straight into appendable storage
-                cap, hr = compressed_length + self.cfg.arena_extra_tokens, self.cfg.arena_headroom
-                k_compressed = CompressedArena.from_pruned(k_pruned.reshape(total_batch_kv, -1, D), "key", cap, hr)
-                v_compressed = CompressedArena.from_pruned(v_pruned.reshape(total_batch_kv, -1, D), "value", cap, hr)
+            if self.cfg.arena and self.cfg.api == "fused":   # (unreachable since the branch above takes every arena prefill; kept for callers that set arena late)
+                k_compressed = CompressedArena.from_pruned(k_pruned.reshape(total_batch_kv, -1, D), "key", None, self.cfg.arena_slack)
+                v_compressed = CompressedArena.from_pruned(v_pruned.reshape(total_batch_kv, -1, D), "value", None, self.cfg.arena_slack)
             else:
                 k_compressed = _compress(k_pruned.reshape(total_batch_kv, -1, D), "key")              # :422-426
                 v_compressed = _compress(v_pruned.reshape(total_batch_kv, -1, D), "value")            # :430-434
@@ -223,11 +226,11 @@ class MustafarAttention:
         """Wrap the two local windows of a reference-layout `past` into appendable buffers."""
         k_c, k_w, v_c, v_w, C, L = past
         if self.cfg.arena and C and not isinstance(k_c, CompressedArena):
-            k_c = CompressedArena.from_reference(k_c, "key", C, C + self.cfg.arena_extra_tokens, self.cfg.arena_headroom)
-            v_c = CompressedArena.from_reference(v_c, "value", C, C + self.cfg.arena_extra_tokens, self.cfg.arena_headroom)
+            k_c = CompressedArena.from_reference(k_c, "key", C, None, self.cfg.arena_slack)
+            v_c = CompressedArena.from_reference(v_c, "value", C, None, self.cfg.arena_slack)
         if isinstance(k_w, Window):
             return (k_c, k_w, v_c, v_w, C, L)
-        cap = self.cfg.residual_length + 256 + 64
+        cap = self.cfg.residual_length + 256   # the longest window: the step that fires the trigger (model :324) holds R + 256 rows
         return (k_c, Window(k_w, cap), v_c, Window(v_w, cap), C, L)
 
     @staticmethod
@@ -303,6 +306,9 @@ class MustafarAttention:
             mask_ptr, mask_stride = attention_mask.data_ptr(), attention_mask.stride(0) if bsz > 1 else attention_mask.shape[3]
         p = lambda t: t.data_ptr() if t is not None else None
         use_arena = isinstance(k_c, CompressedArena)
+        if use_arena:            # a failed asynchronous append is reported before the cache is read again (no host stall)
+            k_c.poll()
+            v_c.poll()
         tail = (q.data_ptr(), k_w.buf.data_ptr(), v_w.buf.data_ptr(), kn.data_ptr(), vn.data_ptr(), w_len, k_w.cap,
                 scores.data_ptr(), ld, out.data_ptr(), ws.data_ptr(), split, C, BH, groups, math.sqrt(D),
                 step_counter.data_ptr() if step_counter is not None else None, mask_ptr, mask_stride, self.num_heads,
@@ -325,8 +331,7 @@ class MustafarAttention:
             if use_arena or (cfg.arena and C == 0):
                 # prune (:325-326) + compress + append (:328-390) of the raw window rows in one launch, no host read
                 if C == 0:
-                    k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, 256 + cfg.arena_extra_tokens,
-                                                             cfg.arena_headroom)
+                    k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, None, cfg.arena_slack)
                 else:
                     CompressedArena.append_window_pair(k_c, v_c, k_w.buf, v_w.buf, 256, kth_k, kth_v)
                 Window.drop_front_pair(k_w, v_w, 256)                                                   # :392-393, in place

@@ -191,3 +191,48 @@ def test_one_head_at_full_length_against_the_c_oracle(name):
             sumabs = np.stack([np.abs(p[b, 0].astype(np.float64)) @ np.abs(dense) for b in range(groups)])[:, None]
         err = np.abs(got.float().cpu().numpy().astype(np.float64) - ref64)
         assert (err <= fp16_bound(ref64, sumabs)).all(), f"{name} {which}: HIP SpMV outside the fp16 bound of the oracle's exact sum"
+
+
+@pytest.mark.parametrize("name", ["c3", "c4", "c5"])
+def test_one_pass_compression_is_bit_exact_at_bench_size(name):
+    """`from_raw_pair` (compress_block_kernel: prune + compress + pack in one read, 124 - 508 blocks per head finding their stream
+    positions from each other's published lengths) at the FULL size bench.py builds its caches at, against
+      * the two-pass form on the same device data (prune_magnitude + convert_*_batched: tile_meta -> block_scan -> tile_pack),
+        compared on the GPU: bitmaps, offsets, every head's stream and length;
+      * the C oracle on ONE kv-head (prune + bitmaps + offsets + stream), bit for bit.
+    (Before round 3 the one-pass form was held bit-exact only up to 1024 tokens x 8 heads.)"""
+    from mustafar_amd import compression
+    from mustafar_amd.cache import CompressedArena
+    Hq, Hkv, s, L, batch = CASES[name]
+    T = ((L - 32) // 256) * 256
+    kth = compression.kth_from_sparsity(s, 128)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    K = torch.randn((batch, Hkv, L, 128), device=DEV, generator=g).half()
+    V = torch.randn((batch, Hkv, L, 128), device=DEV, generator=g).half()
+    K[0, 0, 5, :] = 0.5                       # a row of ties (all 128 kept), a row of zeros, signed zeros: the rule's corners at full size
+    K[-1, -1, T - 1, :] = 0
+    V[0, 0, 7, ::2] = -0.0
+    ka, va = CompressedArena.from_raw_pair(K, V, T, kth, kth)
+    assert ka.tokens == va.tokens == T
+    heads = batch * Hkv
+    for which, arena, X in (("key", ka, K), ("value", va, V)):
+        pruned = compression.prune_magnitude(X[:, :, :T].reshape(heads, T, 128).contiguous(), s)
+        conv = compression.convert_key_batched if which == "key" else compression.convert_value_batched
+        bmp, idx, nzs = conv(pruned)
+        t2 = 2 * T
+        assert torch.equal(arena.bmp[:, :t2], bmp.view(heads, t2)), f"{name} {which}: bitmaps differ from the two-pass form"
+        assert torch.equal(arena.idx[:, :t2 + 1], idx.view(heads, t2 + 1)), f"{name} {which}: offsets differ from the two-pass form"
+        used = arena.used
+        assert [int(u) for u in used] == [n.numel() for n in nzs]
+        for h in range(heads):
+            assert torch.equal(arena.nz[h, :int(used[h])].view(torch.int16), nzs[h].view(torch.int16)), f"{name} {which}: stream of head {h}"
+        # one kv-head against the C oracle (the head that carries the planted corner rows)
+        h = 0
+        x_h = X[0, 0, :T].cpu().numpy()[None]
+        conv_o = orc.convert_key_batched if which == "key" else orc.convert_value_batched
+        obmp, oidx, onzs = conv_o(orc.prune_magnitude(x_h, s))
+        assert np.array_equal(arena.bmp[h, :t2].cpu().numpy(), obmp[0]) and np.array_equal(arena.idx[h, :t2 + 1].cpu().numpy(), oidx[0])
+        assert np.array_equal(arena.nz[h, :int(used[h])].cpu().numpy().view(np.uint16), np.asarray(onzs[0]).view(np.uint16))
+        del pruned, bmp, idx, nzs
+    del K, V, ka, va
+    torch.cuda.empty_cache()

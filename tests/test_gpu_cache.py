@@ -153,8 +153,8 @@ def test_fused_prefill_from_raw_rows_matches_oracle_prune_and_compress(s_k, s_v)
 
 
 def test_fused_prefill_survives_an_underestimated_stream_region():
-    """Constant rows tie at the threshold, so every element is kept (model :107): twice the estimate.  The first attempt
-    raises the device-side overflow flag and packs nothing; the second attempt uses worst-case regions."""
+    """Constant rows tie at the threshold, so every element is kept (model :107): three times the estimate.  The first attempt
+    raises bit 0 of the device flag and reports the length every head needs; the launch is repeated at that size."""
     from mustafar_amd.cache import CompressedArena
     K = torch.full((1, 2, 256, 128), 0.25, device=DEV, dtype=torch.float16)
     V = -K
@@ -339,3 +339,109 @@ def test_one_pass_compression_randomised_against_the_oracle(seed):
     ka, va = CompressedArena.from_raw_pair(K, V, t, compression.kth_from_sparsity(s_k, 128), compression.kth_from_sparsity(s_v, 128))
     _assert_same_as_oracle(ka, _oracle_pruned(K, s_k, t), "key")
     _assert_same_as_oracle(va, _oracle_pruned(V, s_v, t), "value")
+
+
+# ---- round 3: sizing, failure paths ---------------------------------------------------------------------------------------
+def test_arena_is_housed_within_its_slack_and_appends_keep_it_there():
+    """Reserved bytes stay within (1 + slack) x 1.02 of the bytes in use (+ the rounding of the rows to 64 tokens and 1 KB per head)
+    from the prefill on and across triggers -- the half of the metric that counts allocated bytes -- and the contents stay exact
+    through every re-housing (at this size every trigger re-houses)."""
+    from mustafar_amd import compression
+    from mustafar_amd.cache import CompressedArena, DEFAULT_SLACK
+    from mustafar_amd.hook import Window
+    B, H, s = 1, 4, 0.7
+    kth = compression.kth_from_sparsity(s, 128)
+    K0, V0 = _raw(B, H, 768, 101), _raw(B, H, 768, 102)
+    ka, va = CompressedArena.from_raw_pair(K0, V0, 768, kth, kth)
+    allK, allV = [_oracle_pruned(K0, s, 768)], [_oracle_pruned(V0, s, 768)]
+
+    def tight(a):
+        rows = 24 * a.heads * 64          # rows are rounded up to 64 tokens (24 B of bitmaps + offsets per token)
+        return a.bytes_reserved() <= a.bytes_in_use() * (1 + DEFAULT_SLACK) * 1.02 + rows + 1024 * a.heads
+
+    assert tight(ka) and tight(va)
+    for i in range(5):
+        kw, vw = Window(_raw(B, H, 288, 110 + i), 288), Window(_raw(B, H, 288, 120 + i), 288)
+        allK.append(_oracle_pruned(kw.buf, s, 256))
+        allV.append(_oracle_pruned(vw.buf, s, 256))
+        CompressedArena.append_window_pair(ka, va, kw.buf, vw.buf, 256, kth, kth)
+        assert ka.tokens == va.tokens == 768 + 256 * (i + 1)
+        assert tight(ka) and tight(va), (i, ka.bytes_reserved(), ka.bytes_in_use())
+    _assert_same_as_oracle(ka, torch.cat(allK, 1), "key")
+    _assert_same_as_oracle(va, torch.cat(allV, 1), "value")
+
+
+def test_trigger_append_that_outgrows_the_expected_room_is_repeated_at_the_measured_size():
+    """An append of rows full of ties (every element kept: 128 halfs per token against the ~48 the cache's history predicts)
+    sets bit 0 of the device flag; the host re-houses at the lengths the launch reported and repeats it.  Exact afterwards."""
+    from mustafar_amd import compression
+    from mustafar_amd.cache import CompressedArena
+    B, H, s = 1, 3, 0.7
+    kth = compression.kth_from_sparsity(s, 128)
+    K0, V0 = _raw(B, H, 512, 131), _raw(B, H, 512, 132)
+    ka, va = CompressedArena.from_raw_pair(K0, V0, 512, kth, kth)
+    before = (ka.nz_cap, va.nz_cap)
+    kw = torch.full((B, H, 288, 128), 0.75, device=DEV, dtype=torch.float16)
+    vw = _raw(B, H, 288, 133)
+    CompressedArena.append_window_pair(ka, va, kw, vw, 256, kth, kth)
+    assert ka.tokens == va.tokens == 768 and ka.nz_cap > before[0] and int(ka._overflow) == 0
+    assert int(ka.used.min()) >= 256 * 128
+    _assert_same_as_oracle(ka, torch.cat([_oracle_pruned(K0, s, 512), kw[:, :, :256].reshape(H, 256, 128).cpu()], 1), "key")
+    _assert_same_as_oracle(va, torch.cat([_oracle_pruned(V0, s, 512), _oracle_pruned(vw, s, 256)], 1), "value")
+
+
+def test_a_compression_timeout_is_its_own_error_and_leaves_the_cache_as_it_was():
+    """Bit 1 of the device flag (a block gave up waiting for its predecessors' lengths) cannot be provoked on demand; what the host
+    does with it can: the flag is pre-set, as if a block of this very launch had set it."""
+    from mustafar_amd import compression
+    from mustafar_amd.cache import ArenaAppendTimeout, CompressedArena
+    B, H, s = 1, 2, 0.7
+    kth = compression.kth_from_sparsity(s, 128)
+    K0, V0 = _raw(B, H, 256, 141), _raw(B, H, 256, 142)
+    ka, va = CompressedArena.from_raw_pair(K0, V0, 256, kth, kth)
+    ref = [x.clone() for x in ka.to_reference()[:2]]
+    kw, vw = _raw(B, H, 288, 143), _raw(B, H, 288, 144)
+    for a in (ka, va):                                    # room as the call itself would make it, so that the flag tensor stays the one pre-set
+        a._make_room(256, int(a.used.max()) + a._expected_append(256, kth))
+    va._overflow = ka._overflow
+    ka._overflow.fill_(2)
+    with pytest.raises(ArenaAppendTimeout):
+        CompressedArena.append_window_pair(ka, va, kw, vw, 256, kth, kth)
+    assert ka.tokens == va.tokens == 256 and int(ka._overflow) == 0
+    got = ka.to_reference()
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    CompressedArena.append_window_pair(ka, va, kw, vw, 256, kth, kth)      # and the next append goes through
+    assert ka.tokens == 512
+    _assert_same_as_oracle(ka, torch.cat([_oracle_pruned(K0, s, 256), _oracle_pruned(kw, s, 256)], 1), "key")
+
+
+def test_the_one_pass_form_refuses_to_run_without_a_flag():
+    from mustafar_amd import _lib, compression
+    from mustafar_amd.cache import CompressedArena
+    L = _lib.load()
+    K0 = _raw(1, 2, 256, 151)
+    ka, va = CompressedArena.from_raw_pair(K0, K0, 256, 89, 89, cap_tokens=1024)
+    kw = _raw(1, 2, 288, 152)
+    scratch = torch.empty(int(L.mustafar_compress_scratch_bytes(2, 256)), dtype=torch.uint8, device=DEV)
+    tot = torch.zeros(2, dtype=torch.int64, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.mustafar_cache_append_kv(st, kw.data_ptr(), kw.data_ptr(), 288 * 128, 2, 256, 128, 89, 89, ka.view_ptr(), va.view_ptr(), 256,
+                                      tot.data_ptr(), tot.data_ptr(), ka.nz_cap, va.nz_cap, None, scratch.data_ptr()) == 1
+
+
+def test_prefill_from_transposed_layout_k_and_v():
+    """In the model K and V reach the hook as transpose(1, 2) views of [B, L, H, D] projections (RoPE keeps the strides): the
+    arena prefill takes them too (through a contiguous copy) and builds the same cache as from contiguous tensors."""
+    from mustafar_amd.cache import CompressedArena
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    torch.manual_seed(161)
+    B, Hkv, L, D = 2, 2, 600, 128
+    Kt = torch.randn(B, L, Hkv, D, device=DEV).half().transpose(1, 2)
+    Vt = torch.randn(B, L, Hkv, D, device=DEV).half().transpose(1, 2)
+    assert not Kt.is_contiguous()
+    attn = MustafarAttention(MustafarConfig(num_attention_heads=8, num_key_value_heads=Hkv, api="fused", arena=True))
+    past = attn.build_cache(Kt, Vt)
+    assert isinstance(past[0], CompressedArena) and past[4] == 512
+    _assert_same_as_oracle(past[0], _oracle_pruned(Kt, 0.7, 512), "key")
+    _assert_same_as_oracle(past[2], _oracle_pruned(Vt, 0.7, 512), "value")
+    assert torch.equal(past[1], Kt[:, :, 512:]) and torch.equal(past[3], Vt[:, :, 512:])
