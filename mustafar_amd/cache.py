@@ -10,11 +10,11 @@ The format is unchanged (bit order, padding to 8, offsets in half2 units, `nz_of
 read an arena through `mustafar_cache_view` (head strides), and `to_reference()` returns the reference's contiguous list.
 
 Sizing (round 3).  Whatever is allocated beyond the bytes in use counts against the metric's second half (peak KV bytes), so
-an arena is housed at `(1 + slack)` x what it holds (`DEFAULT_SLACK` = 5 %: token rows and stream regions alike) and nothing
+an arena is housed at `(1 + slack)` x what it holds (`DEFAULT_SLACK` = 3 %: token rows and stream regions alike; at c3 that keeps dense / reserved bytes at 2.0) and nothing
 is reserved for a worst-case append any more:
   * an append first makes room for what it EXPECTS to add (the head's measured halfs per token x 1.04) -- re-housing the arena
-    at `(1 + slack)` x the new size when that does not fit (at a 768-token cache that is every trigger, a copy of a few MB,
-    what the reference does with a dozen `torch.cat`s; at 8 k tokens every other trigger);
+    at `(1 + slack)` x the new size when that does not fit (up to ~8 k tokens that is every trigger: one copy of the cache,
+    what the reference does with a dozen `torch.cat`s per trigger anyway; at 16 k tokens every other trigger, at 32 k every fourth);
   * the launch reports every head's true new length and refuses to write past a region (device flag, bit 0); the host reads
     the flag and the lengths right behind the launch (one small device->host read per trigger, as `append()` always had) and, if
     a head did outgrow its region -- rows full of ties keep more than the expected count, model :107 -- re-houses at the
@@ -35,7 +35,7 @@ import torch
 
 from . import _lib
 
-DEFAULT_SLACK = 0.05
+DEFAULT_SLACK = 0.03
 
 
 class ArenaAppendTimeout(RuntimeError):
@@ -325,9 +325,16 @@ class CompressedArena:
 
     def to_reference(self) -> list:
         """[bitmaps int64 [B', 2T], idxs int32 [B', 2T+1], list of B' fp16 streams, nz_offset] (contiguous copies)."""
+        from .compression import pieces_of
         from .hook import FlatStreams, nz_offset_from_idxs
         t = self.tokens * self.TILES_PER_TOKEN
         bmp = self.bmp[:, :t].contiguous()
         idx = self.idx[:, :t + 1].contiguous()
-        per_head: List[torch.Tensor] = [self.nz[h, :int(self.used[h])].clone() for h in range(self.heads)]
-        return [bmp, idx, FlatStreams(per_head), nz_offset_from_idxs(idx, self.heads)]
+        used = [int(u) for u in self.used]
+        offs = [0]
+        for u in used:
+            offs.append(offs[-1] + u)
+        flat = torch.empty((offs[-1],), dtype=torch.float16, device=self.device)
+        for h, u in enumerate(used):
+            flat[offs[h]:offs[h + 1]] = self.nz[h, :u]
+        return [bmp, idx, FlatStreams(pieces_of(flat, offs)), nz_offset_from_idxs(idx, self.heads)]

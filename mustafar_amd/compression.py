@@ -6,7 +6,14 @@ Same arguments, same return types as kernel/compression.py:249-339 and :341-432:
 computed by the HIP kernels in csrc/compress.hip behind the C ABI (include/mustafar_hip.h).  One small
 device->host read (B'+1 int64 offsets) sits between the two passes because the packed sizes define the
 shapes of the returned tensors; the reference needs 1 + 2B' `.item()` syncs for the same reason (:308, :333-334).
-The per-head tensors are views of one packed buffer (the reference clones each slice, :335).
+The per-head tensors are views of one packed buffer (the reference clones each slice, :335) and remember it: they are
+`StreamPiece`s, a tensor subclass whose only behaviour is that
+    torch.cat(list of all the pieces of one buffer, in order)      (model :274, :314: once per layer and decode step)
+returns that buffer itself instead of copying every head's stream again, and that the per-head concatenation of the trigger
+    [torch.cat([old[b], new[b]], dim=0) for b in range(heads)]      (model :368, :390)
+lands, head by head, in ONE new buffer, so that the next `torch.cat` of the resulting list is free again.  Everything else a
+piece is asked to do, it does as the plain tensor it is.  The hook's source is untouched by this: it is the tensors it gets back
+from `convert_*_batched` that know where they live.
 """
 from __future__ import annotations
 
@@ -15,6 +22,67 @@ from typing import List, Tuple
 import torch
 
 from . import _lib
+
+
+class _Backing:
+    """One packed buffer and the pieces it is cut into: offs[b] .. offs[b + 1] (halfs) is head b's stream."""
+    __slots__ = ("buf", "offs", "indices", "succ", "__weakref__")
+
+    def __init__(self, buf: torch.Tensor, offs: List[int]):
+        self.buf, self.offs = buf, offs
+        self.indices = list(range(len(offs) - 1))
+        self.succ = None     # (id of the other backing, backing that takes old + new per head): the trigger's concatenation target
+
+
+class StreamPiece(torch.Tensor):
+    """A head's packed stream: a view into a `_Backing` buffer (`_bk`, `_ix`).  See the module docstring."""
+
+    @staticmethod
+    def wrap(view: torch.Tensor, bk: _Backing, ix: int) -> "StreamPiece":
+        p = view.as_subclass(StreamPiece)
+        p._bk, p._ix = bk, ix
+        return p
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.cat and args and isinstance(args[0], (list, tuple)) and "out" not in kwargs:
+            tensors = args[0]
+            dim = kwargs.get("dim", args[1] if len(args) > 1 else 0)
+            n = len(tensors)
+            if dim == 0 and n and all(type(t) is StreamPiece for t in tensors):
+                bk = tensors[0]._bk
+                if n == len(bk.indices) and [t._ix for t in tensors] == bk.indices and all(t._bk is bk for t in tensors):
+                    return bk.buf                                       # every piece of one buffer, in order: the buffer
+                if n == 2 and tensors[0]._ix == tensors[1]._ix and tensors[0]._bk is not tensors[1]._bk:
+                    return _append_piece(tensors[0], tensors[1])        # the trigger's per-head concatenation
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+def _append_piece(old: StreamPiece, new: StreamPiece) -> torch.Tensor:
+    """torch.cat([old, new]) of head b's old stream and its newly compressed tokens, written into the buffer that will hold
+    every head's concatenation (allocated when the first head asks); returns the view of it (a piece of the new buffer)."""
+    ob, nb, b = old._bk, new._bk, old._ix
+    if len(ob.offs) != len(nb.offs):
+        with torch._C.DisableTorchFunctionSubclass():
+            return torch.cat([old, new], dim=0)
+    if ob.succ is None or ob.succ[0] is not nb:
+        offs = [0]
+        for i in range(len(ob.offs) - 1):
+            offs.append(offs[-1] + (ob.offs[i + 1] - ob.offs[i]) + (nb.offs[i + 1] - nb.offs[i]))
+        ob.succ = (nb, _Backing(torch.empty((offs[-1],), dtype=ob.buf.dtype, device=ob.buf.device), offs))
+    tgt = ob.succ[1]
+    dst = tgt.buf[tgt.offs[b]:tgt.offs[b + 1]]
+    with torch._C.DisableTorchFunctionSubclass():
+        torch.cat([old.as_subclass(torch.Tensor), new.as_subclass(torch.Tensor)], dim=0, out=dst)
+    return StreamPiece.wrap(dst, tgt, b)
+
+
+def pieces_of(flat: torch.Tensor, offs: List[int]) -> List[torch.Tensor]:
+    """Cut a packed buffer into per-head `StreamPiece`s (offs: B' + 1 boundaries in halfs)."""
+    bk = _Backing(flat, list(offs))
+    return [StreamPiece.wrap(flat[offs[b]:offs[b + 1]], bk, b) for b in range(len(offs) - 1)]
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -72,7 +140,7 @@ def _convert(inputs: torch.Tensor, which: str) -> Tuple[torch.Tensor, torch.Tens
                                                             accum.data_ptr(), head_off.data_ptr(),
                                                             packed.data_ptr() if offs[-1] else None)
         _lib.check(err, f"mustafar_compress_pack_{which}")
-    return bitmaps, accum, [packed[offs[b]:offs[b + 1]] for b in range(B)]
+    return bitmaps, accum, pieces_of(packed, offs)
 
 
 def convert_key_batched(inputs: torch.Tensor):

@@ -43,7 +43,7 @@ class MustafarConfig:
     group_size: int = 32          # carried by the reference config, unused on the kernel path
     api: str = "native"           # "reference" | "native" | "fused"
     arena: bool = False           # api="fused": keep the compressed cache in CompressedArena objects (in-place append)
-    arena_slack: float = 0.05       # an arena is housed at (1 + arena_slack) x the rows / stream bytes it holds (cache.py: DEFAULT_SLACK)
+    arena_slack: float = 0.03       # an arena is housed at (1 + arena_slack) x the rows / stream bytes it holds (cache.py: DEFAULT_SLACK)
     # api="fused": this instance's FMA engine ("dot2" | "valu" | "mfma"; None = the process default) and launch structure
     # ("one_pass" | "two_launch"; None = by size).  Carried in every call's `flags` (include/mustafar_hip.h): two instances in
     # one process run what each of them asks for.
@@ -61,15 +61,19 @@ def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:
 
 
 class FlatStreams(list):
-    """The reference's per-head list of packed-nz tensors, plus the same bytes as ONE flat tensor.
-
-    `torch.cat(streams)` (what the model does on every decode step, :274/:314) still works; `streams.flat` is
-    the zero-copy equivalent used by api="native".
-    """
+    """The reference's per-head list of packed-nz tensors.  `streams.flat` is the packed stream of all heads as ONE tensor --
+    `torch.cat(streams)`, what the model does on every decode step (:274/:314), which costs nothing when the elements are the
+    `StreamPiece`s that `convert_*_batched` returns (compression.py: the pieces of one buffer, in order, ARE that buffer)."""
 
     def __init__(self, per_head: List[torch.Tensor], flat: Optional[torch.Tensor] = None):
         super().__init__(per_head)
-        self.flat = flat if flat is not None else (torch.cat(per_head) if len(per_head) else None)
+        self._flat = flat
+
+    @property
+    def flat(self) -> Optional[torch.Tensor]:
+        if self._flat is None and len(self):
+            self._flat = torch.cat(self)
+        return self._flat
 
 
 def nz_offset_from_idxs(idxs: torch.Tensor, heads: int) -> torch.Tensor:

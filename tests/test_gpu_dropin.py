@@ -75,3 +75,29 @@ def test_reference_call_sequence_through_compiled_extension(ref_modules):
         mustafar_package.mustafar_key_formulation(k_bmps.cpu(), torch.cat(k_nzs), k_idxs, k_nz_offset, padded_query, T, D, BH, groups)
     with pytest.raises(RuntimeError, match="contiguous"):
         mustafar_package.mustafar_key_formulation(k_bmps, torch.cat(k_nzs), k_idxs, k_nz_offset, padded_query.transpose(1, 2), T, D, BH, groups)
+
+
+def test_the_hooks_stream_concatenation_costs_nothing(ref_modules):
+    """The unchanged hook re-concatenates every head's stream on every decode step (model :274, :314) and rebuilds the list per head at
+    every trigger (:368, :390).  With the tensors `convert_*_batched` returns, the first is the packed buffer itself (same storage,
+    no kernel) and the second fills one new buffer -- checked here with the model's own statements, on the GPU, K and V."""
+    mustafar_package, compression = ref_modules
+    torch.manual_seed(1)
+    Bkv, T, D = 6, 512, 128
+    for conv in (compression.convert_key_batched, compression.convert_value_batched):
+        old = compression.prune_magnitude(torch.randn(Bkv, T, D, device=DEV).half(), 0.7)
+        new = compression.prune_magnitude(torch.randn(Bkv, 256, D, device=DEV).half(), 0.7)
+        _, _, nzs = conv(old)
+        _, _, new_nzs = conv(new)
+        packed = torch.cat(nzs)                                                            # model :274
+        assert packed.data_ptr() == nzs[0].data_ptr() and packed.numel() == sum(n.numel() for n in nzs)
+        before = torch.cuda.memory_allocated()
+        for _ in range(3):
+            assert torch.cat(nzs).data_ptr() == packed.data_ptr()
+        assert torch.cuda.memory_allocated() <= before, "torch.cat of the pieces allocated something"
+        want = [torch.cat([nzs[b].clone(), new_nzs[b].clone()], dim=0) for b in range(Bkv)]   # plain tensors: the reference's result
+        merged = [torch.cat([nzs[b], new_nzs[b]], dim=0) for b in range(Bkv)]                # model :368
+        for a, b in zip(merged, want):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        whole = torch.cat(merged)
+        assert whole.data_ptr() == merged[0].data_ptr() and torch.equal(whole.view(torch.int16), torch.cat(want).view(torch.int16))

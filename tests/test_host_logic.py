@@ -166,3 +166,35 @@ def test_no_read_of_an_in_flight_scalar_load_in_the_spmv_isa():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main() == 0
+
+
+def test_stream_pieces_make_the_hooks_torch_cat_free():
+    """compression.StreamPiece (CPU tensors suffice): `torch.cat` of all the pieces of one buffer, in order, IS that buffer (model
+    :274, :314); the trigger's per-head `torch.cat([old[b], new[b]])` (model :368, :390) fills one new buffer whose pieces
+    concatenate for free again; anything else falls back to an ordinary copy with ordinary results."""
+    from mustafar_amd.compression import StreamPiece, pieces_of
+    flat = torch.arange(40, dtype=torch.float16)
+    offs = [0, 8, 8, 24, 40]                                   # head 1 is empty
+    ps = pieces_of(flat, offs)
+    assert all(type(p) is StreamPiece for p in ps) and [p.numel() for p in ps] == [8, 0, 16, 16]
+    whole = torch.cat(ps)
+    assert type(whole) is torch.Tensor and whole.data_ptr() == flat.data_ptr() and whole.numel() == 40
+    assert torch.cat(ps, dim=0).data_ptr() == flat.data_ptr() and torch.cat(tuple(ps)).data_ptr() == flat.data_ptr()
+    # not the whole buffer / not in order / mixed with a plain tensor: a copy, with the values torch.cat always gives
+    part = torch.cat(ps[:3])
+    assert part.data_ptr() != flat.data_ptr() and torch.equal(part, flat[:24])
+    perm = torch.cat([ps[2], ps[0], ps[1], ps[3]])
+    assert perm.data_ptr() != flat.data_ptr() and torch.equal(perm, torch.cat([flat[8:24], flat[:8], flat[24:]]))
+    mixed = torch.cat([ps[0], torch.ones(3, dtype=torch.float16)])
+    assert type(mixed) is torch.Tensor and mixed.tolist() == list(range(8)) + [1, 1, 1]
+    # the trigger: new tokens of every head in their own buffer, concatenated per head exactly as the model writes it
+    new = pieces_of(torch.arange(100, 124, dtype=torch.float16), [0, 8, 16, 16, 24])
+    merged = [torch.cat([ps[b], new[b]], dim=0) for b in range(4)]
+    assert all(type(m) is StreamPiece for m in merged)
+    for b in range(4):
+        assert torch.equal(merged[b].as_subclass(torch.Tensor), torch.cat([flat[offs[b]:offs[b + 1]], new[b].as_subclass(torch.Tensor)]))
+    again = torch.cat(merged)
+    assert again.data_ptr() == merged[0].data_ptr() and again.numel() == 64
+    assert torch.equal(again, torch.cat([m.as_subclass(torch.Tensor).clone() for m in merged]))
+    # ordinary tensor behaviour of a piece
+    assert float(ps[0][-1]) == 7.0 and type(ps[2] * 2) is torch.Tensor and ps[3].view(2, 8).shape == (2, 8) and len(ps[2]) == 16

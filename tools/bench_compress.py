@@ -44,9 +44,14 @@ for name in sys.argv[1:] or ["c3", "c4"]:
 
     def fused():
         _lib.check(L.mustafar_cache_append_kv(st, xk.data_ptr(), xv.data_ptr(), T * 128, Bp, T, 128, kth, kth, ka.view_ptr(), va.view_ptr(), 0,
-                                              ka._totals.data_ptr(), va._totals.data_ptr(), ka.nz_cap, va.nz_cap, None, scratch.data_ptr()), "append_kv")
+                                              ka._totals.data_ptr(), va._totals.data_ptr(), ka.nz_cap, va.nz_cap, ka._overflow.data_ptr(), scratch.data_ptr()), "append_kv")
     t_f = timeit(fused, 10)
+    assert int(ka._overflow) == 0
+    # bytes of the one-pass form: the raw K and V blocks are read ONCE each; bitmaps (8 B), offsets (4 B) per tile and the packed
+    # streams are written once
+    in_b = (xk.numel() + xv.numel()) * 2
     out_b = int(ka.used.sum() + va.used.sum()) * 2 + 2 * Bp * tiles * 12
     res.update(fused_prune_compress_kv_us=round(t_f * 1e6, 1), fused_per_side_us=round(t_f * 1e6 / 2, 1),
-               fused_GBps_in_twice_plus_out=round((2 * 2 * xk.numel() * 2 + out_b) / t_f / 1e9, 1))
+               fused_bytes_in=in_b, fused_bytes_out=out_b, fused_GBps_in_once_plus_out=round((in_b + out_b) / t_f / 1e9, 1),
+               fused_frac_of_8TBps=round((in_b + out_b) / t_f / 8e12, 3))
     print(json.dumps(res), flush=True)
