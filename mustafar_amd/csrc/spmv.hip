@@ -1795,18 +1795,21 @@ __global__ __launch_bounds__(kThreads, MF ? 5 : 1) void decode_onepass_kernel(  
 // out[bh, c] = fp16( sum_s w_s * o_s[c] / sum_s w_s * l_s ),  w_s = exp(m_s - max_s m_s)   (the softmax of :304 and the
 // sums of :315-317, merged over the slabs of the row).  One workgroup per row, 256 threads: thread = (channel, parity).
 constexpr int kMaxSlabs = 512;
+// Every wave works out the row's maximum, the slab weights and the denominator for ITSELF (lane = slab, DPP reductions, its own
+// LDS copy of the weights): no barrier before the weighted sum, one behind it to fold the two slab parities.  (Round 2 reduced
+// across the workgroup: five barriers in a kernel that is all latency; 5.4 -> 4.x us per layer at c3.)
 __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml,
                                                              int S, h16* __restrict__ out, int BH)
 {
-    __shared__ float wgt[kMaxSlabs];
-    __shared__ float sh[4];
+    __shared__ float wgt_all[4][kMaxSlabs];
     __shared__ float part[kD];
-    const int bh = blockIdx.x, tid = threadIdx.x;
+    const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int c = tid & (kD - 1), par = tid >> 7;
+    float* wgt = wgt_all[tid >> 6];
     const int64_t total = (int64_t)BH * kD;
     const float* src = ws_o + (int64_t)bh * kD + c;
     // The first 64 slabs' outputs are requested BEFORE the weights are known: the loads fly while the maxima / sums are
-    // loaded and reduced (the kernel is two dependent memory round trips otherwise; 62-68 slabs at c3).
+    // loaded and reduced (the kernel is two dependent memory round trips otherwise; 36-68 slabs at c3).
     constexpr int kEarly = 32;   // per thread: slabs par, par + 2, ..., par + 62
     float v[kEarly];
 #pragma unroll
@@ -1814,14 +1817,32 @@ __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __rest
         const int k = par + 2 * i;
         v[i] = (k < S) ? src[(int64_t)k * total] : 0.f;
     }
-    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;   // slabs tid and tid + 256
-    if (tid < S) { m0 = ws_ml[((int64_t)tid * BH + bh) * 2]; l0 = ws_ml[((int64_t)tid * BH + bh) * 2 + 1]; }
-    if (tid + 256 < S) { m1 = ws_ml[((int64_t)(tid + 256) * BH + bh) * 2]; l1 = ws_ml[((int64_t)(tid + 256) * BH + bh) * 2 + 1]; }
-    const float M = block_reduce<4>(fmaxf(m0, m1), true, sh);
-    const float w0 = (l0 > 0.f) ? __expf(m0 - M) : 0.f, w1 = (l1 > 0.f) ? __expf(m1 - M) : 0.f;
-    if (tid < S) wgt[tid] = w0;
-    if (tid + 256 < S) wgt[tid + 256] = w1;
-    const float denom = block_reduce<4>(w0 * l0 + w1 * l1, false, sh);   // (its barriers also publish wgt[])
+    constexpr int kPer = kMaxSlabs / 64;   // slabs lane, lane + 64, ... of the row, in every wave
+    float m[kPer], l[kPer];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+        const int k = lane + 64 * i;
+        m[i] = -INFINITY;
+        l[i] = 0.f;
+        if (k < S) {
+            const float2 ml = *reinterpret_cast<const float2*>(ws_ml + ((int64_t)k * BH + bh) * 2);
+            m[i] = ml.x;
+            l[i] = ml.y;
+        }
+        mx = fmaxf(mx, m[i]);
+    }
+    const float M = wave_max(mx);
+    float dsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+        const int k = lane + 64 * i;
+        const float w = (l[i] > 0.f) ? __expf(m[i] - M) : 0.f;
+        if (k < S) wgt[k] = w;
+        dsum += w * l[i];
+    }
+    const float denom = wave_sum(dsum);
+    __builtin_amdgcn_wave_barrier();   // (the wave's own LDS writes, read back below: ordered within the wave)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int i = 0; i < kEarly; i += 4) {   // (slabs beyond S were read as zero; their weights are never read)
@@ -1946,14 +1967,23 @@ __device__ __forceinline__ void fma8_d2(const u32x4 (&c)[4], Gathered2& g, float
                    MUSTAFAR_COPS(2), MUSTAFAR_COPS(3));
 }
 
-// prefetch_meta without a divergent region (every lane loads; lanes 25.. repeat lane 24's line): the lean kernel calls it inside
-// its block loop, right in front of asm statements that own EXEC.
+// prefetch_meta without a divergent region (every lane loads; the lanes beyond the last sector repeat it): the lean kernels call it
+// inside their block loops, right in front of asm statements that own EXEC.  Tiles [T0, T0 + NT) of the block (a wave of the pair
+// form asks for its own half only), one 4-byte load per 64-byte line: NT / 8 lines of bitmaps, NT / 16 + 2 of offsets (the row may
+// start anywhere).  (One load per 32-byte sector measured the same: L2 fills whole lines.  MUSTAFAR_PF_SECTOR: experiment knob.)
+#ifndef MUSTAFAR_PF_SECTOR
+#define MUSTAFAR_PF_SECTOR 64
+#endif
+template <int T0, int NT>
 __device__ __forceinline__ uint32_t prefetch_meta_all(const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t, int lane)
 {
-    const int k = lane < 24 ? lane : 24;
-    const unsigned char* a = reinterpret_cast<const unsigned char*>(bmp_t) + k * 64;
-    const unsigned char* b = reinterpret_cast<const unsigned char*>(idx_t) + (k - 16) * 64;
-    return *reinterpret_cast<const uint32_t*>(k < 16 ? a : b);
+    constexpr int kSec = MUSTAFAR_PF_SECTOR;
+    constexpr int kB = NT * 8 / kSec, kI = (NT * 4 + kSec - 1) / kSec + 1;
+    static_assert(kB + kI <= 64, "one load per sector and lane");
+    const int k = lane < kB + kI - 1 ? lane : kB + kI - 1;
+    const unsigned char* a = reinterpret_cast<const unsigned char*>(bmp_t + T0) + k * kSec;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(idx_t + T0) + (k - kB) * kSec;
+    return *reinterpret_cast<const uint32_t*>(k < kB ? a : b);
 }
 
 // One staged chunk (32 tiles) of the lean kernel; the step schedule is chunk32's.
@@ -2113,9 +2143,9 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_lean_kernel(
         const uint32_t* vit = vi + (int64_t)tb * kTilesPerTb;
         // everything the block needs from memory before its streams is requested up front: metadata lines into L2, the chunk
         // bounds of both sides, the mask column of the lane's token
-        const uint32_t pfk = prefetch_meta_all(kbt, kit, lane);
+        const uint32_t pfk = prefetch_meta_all<0, 128>(kbt, kit, lane);
         const uint32_t bnd_k = bnd_load(kit, lane);
-        const uint32_t pfv = prefetch_meta_all(vbt, vit, lane);
+        const uint32_t pfv = prefetch_meta_all<0, 128>(vbt, vit, lane);
         const uint32_t bnd_v = bnd_load(vit, lane);
         const h16 mk = mrow ? mrow[tb * 64 + lane] : (h16)0.f;   // (mrow is wave-uniform: a scalar branch)
         float s[G];
@@ -2269,7 +2299,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         h16 mk = (h16)0.f;
         if (active) {
             const uint32_t bnd_k = bnd_load(kit, lane);
-            const uint32_t pfk = prefetch_meta_all(kbt, kit, lane);
+            const uint32_t pfk = odd ? prefetch_meta_all<64, 64>(kbt, kit, lane) : prefetch_meta_all<0, 64>(kbt, kit, lane);   // (the wave's own half)
             if (mrow) mk = mrow[tb * 64 + lane];
             if (odd) lean_block_phase<ENG, kD * 2, false, 2, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG);
             else     lean_block_phase<ENG, kD * 2, false, 0, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG);
@@ -2278,7 +2308,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
             // their use: requested at the block's start (~10 us ahead) the lines were often gone from L2 again by the time the
             // scalar loads came for them (c3: 44.4 -> 43.7 us; without any prefetch the launch takes 62 us)
             bnd_v = bnd_load(vit, lane);
-            pfv = prefetch_meta_all(vbt, vit, lane);
+            pfv = odd ? prefetch_meta_all<64, 64>(vbt, vit, lane) : prefetch_meta_all<0, 64>(vbt, vit, lane);
             if (odd) {
 #pragma unroll
                 for (int h = 0; h < G; h++) xch[h * 64 + lane] = s[h];

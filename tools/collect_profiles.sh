@@ -1,19 +1,33 @@
 #!/bin/bash
 # Round evidence in one GPU call: usage (GPU box, repo root): tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>/
-#   bench line (driver form), rocprofv3 kernel stats of the same command, SQ counters (c5, both FMA engines), TCC traffic (c3),
-#   mem_spd harness, prefill-compression and append timings, launch-form sweep
-TAG=${1:-r02}; R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O
-tools/prof_traffic.sh ${TAG} c3 > $O/traffic_c3_tcc.txt 2>&1; python3 tools/make_traffic_json.py gpurun_out/traffic_${TAG} c3 >> $O/traffic_c3_tcc.txt 2>&1; cp profiles/hbm_traffic.json $O/hbm_traffic.json; echo "traffic done"
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err && echo "bench done"
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference-api --no-other-configs --no-trigger-leg > $O/bench_c3_under_rocprof.json 2>/dev/null )
-cp $(ls $O/rocprof_bench/*/*kernel_stats.csv | head -1) $O/bench_c3_kernel_stats.csv && echo "rocprof done"
-tools/prof_pmc.sh ${TAG}_valu c5 > /dev/null 2>&1; cp gpurun_out/pmc_${TAG}_valu.txt $O/pmc_sq_c5_valu.txt
-PROF_FUSED=1 tools/prof_pmc.sh ${TAG}_valu_c3 c3 > /dev/null 2>&1; for p in A B C; do python3 tools/pmc_summary.py gpurun_out/pmc_${TAG}_valu_c3_$p --match onepass_kernel; done > $O/pmc_sq_c3_valu_onepass.txt
-PROF_FUSED=1 MUSTAFAR_FMA_ENGINE=mfma tools/prof_pmc.sh ${TAG}_mfma_c3 c3 > /dev/null 2>&1; for p in A B C; do python3 tools/pmc_summary.py gpurun_out/pmc_${TAG}_mfma_c3_$p --match onepass_kernel; done > $O/pmc_sq_c3_mfma_onepass.txt
-MUSTAFAR_FMA_ENGINE=mfma tools/prof_pmc.sh ${TAG}_mfma c5 > /dev/null 2>&1; cp gpurun_out/pmc_${TAG}_mfma.txt $O/pmc_sq_c5_mfma.txt; echo "pmc done"
-python3 tools/mem_spd.py --api fused reference > $O/mem_spd.txt 2>&1; python3 tools/mem_spd.py --api fused --graph >> $O/mem_spd.txt 2>&1; echo "mem_spd done"
-python3 tools/bench_compress.py c3 c4 2>&1 | grep cfg > $O/compress.txt; python3 tools/bench_append.py 2>&1 | grep cfg > $O/append.txt
-python3 tools/microbench.py --cfg c2 c3 c4 c5 --rows 1 --iters 30 2>&1 | grep cfg > $O/microbench_valu.txt
-MUSTAFAR_FMA_ENGINE=mfma python3 tools/microbench.py --cfg c3 c4 c5 --rows 1 --iters 30 2>&1 | grep cfg > $O/microbench_mfma.txt
-python3 tools/microbench.py --cfg c3 c5 --rows 1 --iters 30 --adversarial 2>&1 | grep cfg > $O/microbench_adversarial.txt
+#   TCC traffic (c3), bench line (driver form), rocprofv3 kernel stats of the same command, SQ counters of the one-pass launch
+#   per engine (c3, c5), mem_spd harness, prefill-compression and append timings, the two reference entry points.
+# Every profiler pass starts from an empty directory and keeps its output in a .err file; a failing step stops the script (set -e),
+# so nothing stale can be copied into profiles/ and a fault under the profiler does not go unnoticed.
+set -e
+TAG=${1:-r03}; R=$(pwd); O=$R/gpurun_out/$TAG; rm -rf "$O"; mkdir -p "$O"
+one_csv() { local n; n=$(ls $1 2>/dev/null | wc -l); [ "$n" = "1" ] || { echo "expected exactly one file for $1, found $n"; exit 1; }; ls $1; }
+
+tools/prof_traffic.sh ${TAG} c3 > $O/traffic_c3_tcc.txt 2> $O/traffic_c3_tcc.err
+python3 tools/make_traffic_json.py gpurun_out/traffic_${TAG} c3 >> $O/traffic_c3_tcc.txt; cp profiles/hbm_traffic.json $O/hbm_traffic.json; echo "traffic done"
+
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench done"
+
+rm -rf $O/rocprof_bench
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference-api --no-other-configs --no-trigger-leg > $O/bench_c3_under_rocprof.json 2> $O/rocprof_bench.err)
+cp $(one_csv "$O/rocprof_bench/*/*kernel_stats.csv") $O/bench_c3_kernel_stats.csv; echo "rocprof done"
+
+for E in dot2 valu mfma; do
+  PROF_FUSED=1 MUSTAFAR_FMA_ENGINE=$E tools/prof_pmc.sh ${TAG}_${E}_c3 c3 > /dev/null
+  grep -v "spmv_kernel\|^$" gpurun_out/pmc_${TAG}_${E}_c3.txt > $O/pmc_sq_c3_${E}_onepass.txt || true
+  PROF_FUSED=1 MUSTAFAR_FMA_ENGINE=$E tools/prof_pmc.sh ${TAG}_${E}_c5 c5 > /dev/null
+  cp gpurun_out/pmc_${TAG}_${E}_c5.txt $O/pmc_sq_c5_${E}.txt
+done; echo "pmc done"
+
+python3 tools/mem_spd.py --api fused reference > $O/mem_spd.txt 2> $O/mem_spd.err; python3 tools/mem_spd.py --api fused --graph >> $O/mem_spd.txt 2>> $O/mem_spd.err; echo "mem_spd done"
+python3 tools/bench_compress.py c3 c4 2> $O/compress.err | grep cfg > $O/compress.txt
+python3 tools/bench_append.py 2> $O/append.err | grep cfg > $O/append.txt
+MUSTAFAR_FMA_ENGINE=valu python3 tools/microbench.py --cfg c2 c3 c4 c5 --rows 1 --iters 30 2> $O/microbench.err | grep cfg > $O/microbench_valu.txt
+MUSTAFAR_FMA_ENGINE=mfma python3 tools/microbench.py --cfg c3 c4 c5 --rows 1 --iters 30 2>> $O/microbench.err | grep cfg > $O/microbench_mfma.txt
+python3 tools/quick.py --cfg c3 c4 c5 --set dot2 valu mfma valu:onepass=0 valu:lean=0 2> $O/quick.err | grep cfg > $O/structures.txt
 echo "all done"; ls $O
