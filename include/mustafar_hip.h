@@ -205,6 +205,13 @@ int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int
                              int kth_v, const mustafar_cache_view* k_dst, const mustafar_cache_view* v_dst, int old_tokens,
                              int64_t* k_head_total, int64_t* v_head_total, int64_t k_region_halfs, int64_t v_region_halfs,
                              int32_t* overflow_flag, void* scratch);
+/*
+ * Move a cache into another view (larger rows / regions: cache.py re-houses an arena when an append does not fit) -- the bitmaps
+ * and offsets of the first `tokens` tokens and the first `stream_halfs` halfs of every head's stream, one launch.  `dst` has
+ * equally spaced stream regions (nz_head_stride > 0); its nz_offset array is written.  tokens % 64 == 0, stream_halfs % 8 == 0.
+ */
+int mustafar_cache_rehouse(void* stream, const mustafar_cache_view* src, const mustafar_cache_view* dst, int Bp, int tokens,
+                           int64_t stream_halfs);
 /* Window slide of the trigger (model :392-393) in place: rows [drop, len) of every head move to the front (at most 64 rows stay). */
 int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int64_t head_stride, int Bp, int len, int drop);
 

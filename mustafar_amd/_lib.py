@@ -41,6 +41,7 @@ SIGNATURES = {
     "mustafar_compress_scratch_bytes": (_i64, [_i32, _i32]),
     "mustafar_cache_append_kv": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _view_p, _view_p, _i32, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mustafar_window_drop_front": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32]),
+    "mustafar_cache_rehouse": (_i32, [_vp, _view_p, _view_p, _i32, _i32, _i64]),
     "mustafar_decode_workspace_bytes": (_i64, [_i32] * 4),
     "mustafar_set_fma_engine": (_i32, [_i32]),
     "mustafar_get_fma_engine": (_i32, []),

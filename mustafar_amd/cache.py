@@ -63,25 +63,44 @@ class CompressedArena:
         self.heads, self.which, self.device, self.slack = heads, which, device, slack
         self.tokens = 0
         self._alloc(cap_tokens, nz_cap)
+        self._init_empty()
 
     # ---- storage ---------------------------------------------------------------------------------------------
     def _alloc(self, cap_tokens: int, nz_cap: int):
+        """ONE device allocation per arena, carved into the four arrays of the format (+ the per-head lengths and the flag the
+        append launch writes): a re-housing is one allocation and one copy launch (mustafar_cache_rehouse)."""
         tiles = cap_tokens * self.TILES_PER_TOKEN
         self.cap_tokens, self.nz_cap = cap_tokens, nz_cap
-        self.bmp = torch.empty((self.heads, tiles), dtype=torch.int64, device=self.device)
-        self.idx = torch.empty((self.heads, tiles + 1), dtype=torch.int32, device=self.device)
-        self.idx[:, 0] = 0
-        self.nz = torch.empty((self.heads, nz_cap), dtype=torch.float16, device=self.device)
-        self.nz_offset = (torch.arange(self.heads, dtype=torch.int64, device=self.device) * (nz_cap // 8)).to(torch.int32)
-        self._totals = torch.empty(self.heads, dtype=torch.int64, device=self.device)
-        self._used = torch.zeros(self.heads, dtype=torch.int64)   # host copy of every head's stream length (halfs)
-        self._host_totals = None                                    # pinned landing area of an asynchronous append's lengths
-        self._pending = None                                        # (event, tokens appended) behind an asynchronous append
-        self._overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        H = self.heads
+        sizes = (("bmp", H * tiles * 8), ("nz", H * nz_cap * 2), ("idx", H * (tiles + 1) * 4), ("nz_offset", H * 4), ("totals", H * 8),
+                 ("flag", 4))
+        offs, total = {}, 0
+        for name, n in sizes:
+            offs[name] = total
+            total = _round_up(total + n, 256)
+        self._buf = buf = torch.empty(total, dtype=torch.uint8, device=self.device)
+        cut = lambda name, n, dt: buf[offs[name]:offs[name] + n].view(dt)
+        self.bmp = cut("bmp", H * tiles * 8, torch.int64).view(H, tiles)
+        self.idx = cut("idx", H * (tiles + 1) * 4, torch.int32).view(H, tiles + 1)
+        self.nz = cut("nz", H * nz_cap * 2, torch.float16).view(H, nz_cap)
+        self.nz_offset = cut("nz_offset", H * 4, torch.int32)
+        self._totals = cut("totals", H * 8, torch.int64)
+        self._overflow = cut("flag", 4, torch.int32)
+        self._used = torch.zeros(H, dtype=torch.int64)   # host copy of every head's stream length (halfs)
+        self._host_totals = None                           # pinned landing area of an asynchronous append's lengths
+        self._pending = None                               # (event, tokens appended) behind an asynchronous append
         self._host_flag = None
+        self._fresh = True                                 # nz_offset / idx[:, 0] / flag not yet written (done by the first use)
         self._view = _lib.CacheView(self.bmp.data_ptr(), self.nz.data_ptr(), self.idx.data_ptr(), self.nz_offset.data_ptr(),
                                     tiles, tiles + 1,
-                                    nz_cap // 8 if (self.heads * (nz_cap // 8) < 2 ** 32 and os.environ.get("MUSTAFAR_NZ_STRIDE", "1") != "0") else 0)
+                                    nz_cap // 8 if (H * (nz_cap // 8) < 2 ** 32 and os.environ.get("MUSTAFAR_NZ_STRIDE", "1") != "0") else 0)
+
+    def _init_empty(self):
+        """An arena that starts empty: stream starts of the heads, offset 0 of every head, flag 0."""
+        self.nz_offset.copy_((torch.arange(self.heads, dtype=torch.int64, device=self.device) * (self.nz_cap // 8)).to(torch.int32))
+        self.idx[:, 0] = 0
+        self._overflow.zero_()
+        self._fresh = False
 
     @property
     def view(self) -> "_lib.CacheView":
@@ -133,16 +152,27 @@ class CompressedArena:
         return sum(x.numel() * x.element_size() for x in (self.bmp, self.idx, self.nz, self.nz_offset))
 
     def _rehouse(self, cap_tokens: int, nz_cap: int):
-        """Move the cache into rows of `cap_tokens` tokens and stream regions of `nz_cap` halfs (never below what it holds)."""
-        old = (self.bmp, self.idx, self.nz, self.used.clone(), self.tokens)   # (resolves a pending asynchronous append)
-        assert cap_tokens >= self.tokens and nz_cap >= (int(self.used.max()) if self.tokens else 0)
-        self._alloc(cap_tokens, nz_cap)
-        o_bmp, o_idx, o_nz, used, tokens = old
-        t = tokens * self.TILES_PER_TOKEN
-        self.bmp[:, :t] = o_bmp[:, :t]
-        self.idx[:, :t + 1] = o_idx[:, :t + 1]
+        """Move the cache into rows of `cap_tokens` tokens and stream regions of `nz_cap` halfs (never below what it holds):
+        one allocation, one launch (mustafar_cache_rehouse); the old storage is released when the copy has been enqueued."""
+        used, tokens = self.used.clone(), self.tokens              # (resolves a pending asynchronous append)
         m = int(used.max()) if tokens else 0
-        self.nz[:, :m] = o_nz[:, :m]
+        assert cap_tokens >= tokens and nz_cap >= m
+        old_buf, old_view, old = self._buf, self._view, (self.bmp, self.idx, self.nz)   # (old_buf keeps the source alive across the launch)
+        self._alloc(cap_tokens, nz_cap)
+        if self._view.nz_head_stride != 0:
+            with torch.cuda.device(self.device):
+                err = _lib.load().mustafar_cache_rehouse(torch.cuda.current_stream(self.device).cuda_stream, ctypes.byref(old_view),
+                                                         ctypes.byref(self._view), self.heads, tokens, _round_up(m, 8))
+            _lib.check(err, "mustafar_cache_rehouse")
+            self._overflow.zero_()
+            self._fresh = False
+        else:   # (MUSTAFAR_NZ_STRIDE=0, an experiment switch: the views carry no stream stride; tensor copies instead)
+            self._init_empty()
+            t2 = tokens * self.TILES_PER_TOKEN
+            self.bmp[:, :t2] = old[0][:, :t2]
+            self.idx[:, :t2 + 1] = old[1][:, :t2 + 1]
+            self.nz[:, :m] = old[2][:, :m]
+        del old_buf, old
         self.used, self.tokens = used, tokens
 
     def _make_room(self, t: int, need_halfs: int) -> None:
@@ -246,8 +276,15 @@ class CompressedArena:
                     a.tokens += t
                 return
             for attempt in range(2):
-                flag = int(CompressedArena._launch_pair(k_arena, v_arena, k_rows, v_rows, t, kth_k, kth_v).item())   # (waits for the launch)
-                totals = (k_arena._totals.cpu(), v_arena._totals.cpu())
+                CompressedArena._launch_pair(k_arena, v_arena, k_rows, v_rows, t, kth_k, kth_v)
+                # flag and lengths: three small copies into pinned memory, ONE wait (for the launch and the copies)
+                host = k_arena._host_landing()
+                host[0][:1].copy_(k_arena._overflow, non_blocking=True)
+                host[1].copy_(k_arena._totals, non_blocking=True)
+                host[2].copy_(v_arena._totals, non_blocking=True)
+                torch.cuda.current_stream(dev).synchronize()
+                flag = int(host[0][0])
+                totals = (host[1].clone(), host[2].clone())
                 if flag:
                     k_arena._overflow.zero_()
                 if flag & 2:
@@ -261,6 +298,13 @@ class CompressedArena:
                     raise RuntimeError("CompressedArena: a head outgrew a stream region sized from the launch's own report: this is a bug")
                 for a, tot in zip((k_arena, v_arena), totals):     # bit 0: the lengths the launch reported are exact: house them and repeat
                     a._make_room(t, int(tot.max()))
+
+    def _host_landing(self):
+        h = getattr(self, "_landing", None)
+        if h is None:
+            h = self._landing = (torch.zeros(2, dtype=torch.int32).pin_memory(), torch.zeros(self.heads, dtype=torch.int64).pin_memory(),
+                                 torch.zeros(self.heads, dtype=torch.int64).pin_memory())
+        return h
 
     def _scratch_for(self, t: int) -> torch.Tensor:
         n = int(_lib.load().mustafar_compress_scratch_bytes(self.heads, t))

@@ -581,6 +581,39 @@ __global__ __launch_bounds__(kThreads) void window_drop_front_kernel(uint16_t* k
     }
 }
 
+// Re-housing of a cache (cache.py: an arena moved into larger rows / regions): the three arrays of every head in ONE launch.
+// grid: x = 16-KiB pieces of a head's largest array, y = head, z = array (0 bitmaps, 1 offsets, 2 stream); z = 0 also writes
+// the destination's nz_offset (equally spaced regions).
+__global__ __launch_bounds__(kThreads) void cache_rehouse_kernel(const uint64_t* s_bmp, const uint32_t* s_idx, const uint16_t* s_nz,
+                                                                 const uint32_t* s_off, int64_t s_bmp_stride, int64_t s_idx_stride,
+                                                                 uint64_t* d_bmp, uint32_t* d_idx, uint16_t* d_nz, uint32_t* d_off,
+                                                                 int64_t d_bmp_stride, int64_t d_idx_stride, uint32_t d_nz_stride,
+                                                                 int64_t tiles, int64_t nz_halfs)
+{
+    const int h = blockIdx.y, which = blockIdx.z;
+    const int64_t piece = (int64_t)blockIdx.x * 1024 + threadIdx.x;   // 16-byte units, 4 per thread and piece
+    if (which == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) d_off[h] = (uint32_t)h * d_nz_stride;
+        const uint4* src = reinterpret_cast<const uint4*>(s_bmp + h * s_bmp_stride);
+        uint4* dst = reinterpret_cast<uint4*>(d_bmp + h * d_bmp_stride);
+        const int64_t n = tiles / 2;                                  // (tiles is a multiple of 128; rows start 16-byte aligned)
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int64_t p = piece + i * 256; if (p < n) dst[p] = src[p]; }
+    } else if (which == 1) {
+        const uint32_t* src = s_idx + h * s_idx_stride;               // (rows of 2 cap + 1 words: no alignment to speak of)
+        uint32_t* dst = d_idx + h * d_idx_stride;
+        const int64_t n = tiles + 1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int64_t p = (int64_t)blockIdx.x * 4096 + threadIdx.x + i * 256; if (p < n) dst[p] = src[p]; }
+    } else {
+        const uint4* src = reinterpret_cast<const uint4*>(s_nz) + (int64_t)s_off[h];
+        uint4* dst = reinterpret_cast<uint4*>(d_nz) + (int64_t)h * d_nz_stride;
+        const int64_t n = nz_halfs / 8;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int64_t p = piece + i * 256; if (p < n) dst[p] = src[p]; }
+    }
+}
+
 // MUSTAFAR_COMPRESS=twopass keeps the round-2 two-pass form of the fused calls (pass 1 + scan + pass 2); default: one pass.
 inline bool one_pass_compress()
 {
@@ -773,6 +806,26 @@ int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int
     const int err = launch_meta(st, s, 2, Bp, t, static_cast<int32_t*>(scratch), overflow_flag, false);
     if (err) return err;
     return launch_pack(st, s, 2, Bp, t, overflow_flag);
+}
+
+int mustafar_cache_rehouse(void* stream, const mustafar_cache_view* src, const mustafar_cache_view* dst, int Bp, int tokens,
+                           int64_t stream_halfs)
+{
+    const int64_t tiles = (int64_t)tokens * kD / 64;
+    if (!src || !dst || Bp < 1 || tokens < 0 || (tokens & 63) || stream_halfs < 0 || (stream_halfs & 7) || !src->bmp || !src->idx ||
+        !src->nz || !src->nz_offset || !dst->bmp || !dst->idx || !dst->nz || !dst->nz_offset || dst->nz_head_stride <= 0 ||
+        stream_halfs > 8 * dst->nz_head_stride || (src->bmp_head_stride ? src->bmp_head_stride : tiles) < tiles ||
+        (dst->bmp_head_stride ? dst->bmp_head_stride : tiles) < tiles || (src->idx_head_stride ? src->idx_head_stride : tiles + 1) < tiles + 1 ||
+        (dst->idx_head_stride ? dst->idx_head_stride : tiles + 1) < tiles + 1)
+        return MUSTAFAR_EINVAL;
+    const int64_t largest = stream_halfs * 2 > tiles * 8 ? stream_halfs * 2 : tiles * 8;   // bytes of a head's largest array
+    const unsigned gx = (unsigned)((largest + 16383) / 16384 > 0 ? (largest + 16383) / 16384 : 1);
+    cache_rehouse_kernel<<<dim3(gx, Bp, 3), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        src->bmp, src->idx, static_cast<const uint16_t*>(src->nz), src->nz_offset, src->bmp_head_stride ? src->bmp_head_stride : tiles,
+        src->idx_head_stride ? src->idx_head_stride : tiles + 1, dst->bmp, dst->idx, static_cast<uint16_t*>(dst->nz), dst->nz_offset,
+        dst->bmp_head_stride ? dst->bmp_head_stride : tiles, dst->idx_head_stride ? dst->idx_head_stride : tiles + 1,
+        (uint32_t)dst->nz_head_stride, tiles, stream_halfs);
+    return (int)hipGetLastError();
 }
 
 int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int64_t head_stride, int Bp, int len, int drop)

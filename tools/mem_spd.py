@@ -96,10 +96,13 @@ class Generator:
         counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         box = {"g": None, "since": 0, "out": None}
 
+        pool = torch.cuda.graph_pool_handle()   # one pool for the graphs of this decode loop (a re-capture reuses the blocks of the graph it
+                                                # replaces; the handle dies with the loop: a pool must not outlive its last graph)
+
         def capture():
             counter.zero_()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, pool=pool):
                 for l in range(L):
                     box["out"], _ = attn.decode_fused(self.dq[l], self.dk[l], self.dv[l], state[l], step_counter=counter)
                 _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream(self.dev).cuda_stream, counter.data_ptr(), 1), "counter_add")
