@@ -80,6 +80,11 @@ def check(asm_text):
             divergent += 1
         elif op == "s_or_b64" and args[:2] == ["exec", "exec"] and divergent:
             divergent -= 1
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64") and not in_asm:
+            # control does not fall through: what follows is reached by jumps only, from places whose own waits were walked
+            # where they stand (the compiler's out-of-line blocks load kernel arguments and jump back to the wait)
+            pending = set()
+            continue
         if op.startswith("s_waitcnt"):
             if "lgkmcnt(0)" in code or re.fullmatch(r"s_waitcnt\s+0", code):
                 pending, waits = set(), waits + 1
