@@ -1967,6 +1967,67 @@ __device__ __forceinline__ void fma8_d2(const u32x4 (&c)[4], Gathered2& g, float
                    MUSTAFAR_COPS(2), MUSTAFAR_COPS(3));
 }
 
+// MUSTAFAR_META_EARLY (default): the NEXT step's bitmaps and offsets are requested in front of this step's gathers, so that the one
+// wait of the step (every lgkmcnt wait is a full drain) covers LDS and scalar-memory latency at once; 0: requested behind the
+// gather wait and waited for behind the FMAs (rounds 1-2: two waits per step, the second one all scalar-memory latency).
+// 1 = the matrix-pipe form only (its coefficients sit in LDS); 2 = the vector engines too (experiment: does not fit their registers).
+#ifndef MUSTAFAR_META_EARLY
+#define MUSTAFAR_META_EARLY 1
+#endif
+
+// The matrix-pipe engine on the lean addressing: the dot2 form's gather (tile pairs packed in one register, exact zeros where a lane
+// has no element), then per FOUR tiles one v_mfma_f32_4x4x4_16B_f16 in place of eight v_dot2 -- the lane's A fragment is the four
+// coefficient halfs of head (lane % 4), read with one ds_read_b64 from a [4 heads][coefficients] table in LDS at ctab_lane =
+// table + (lane % 4) * row stride (layout and roles: the note at GatheredClean).  CBASE = byte offset of the chunk's first
+// coefficient in a table row.  Per tile: 2 v_mbcnt + v_lshl_add + v_mov (zero) + 1/2 v_or + 1/4 v_mfma.
+template <int OFF>
+__device__ __forceinline__ void coefm_issue_at(uint32_t ctab_lane, uint64_t& a0, uint64_t& a1)
+{
+    asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4" : "=&v"(a0), "=&v"(a1) : "v"(ctab_lane), "i"(OFF), "i"(OFF + 8));
+}
+__device__ __forceinline__ void gatherm_wait(Gathered2& g, uint64_t& a0, uint64_t& a1)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]), "+v"(g.t[7]),
+                   "+v"(a0), "+v"(a1));
+}
+__device__ __forceinline__ void fma8_m2(const Gathered2& g, uint64_t a0, uint64_t a1, f32x4& acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a0), pack4(g.t[0], g.t[1], g.t[2], g.t[3]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a1), pack4(g.t[4], g.t[5], g.t[6], g.t[7]), acc, 0, 0, 0);
+}
+template <int TOFF, int CBASE>
+__device__ __forceinline__ void chunk32_mfma_at(uint32_t adj, const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
+                                                uint32_t ctab_lane, f32x4& acc)
+{
+    MetaB cur, nxt;
+    metab_issue_at<TOFF>(cur, bmp_t, idx_t);
+    metab_wait(cur);
+#define MUSTAFAR_STEP(S)                                    \
+    {                                                       \
+        Gathered2 g;                                        \
+        uint64_t a0, a1;                                    \
+        if constexpr (MUSTAFAR_META_EARLY) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t); \
+        gather8_d2(cur, adj, g);                            \
+        coefm_issue_at<CBASE + 16 * S>(ctab_lane, a0, a1);  \
+        gatherm_wait(g, a0, a1);                            \
+        if constexpr (!MUSTAFAR_META_EARLY) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t); \
+        fma8_m2(g, a0, a1, acc);                            \
+        if constexpr (MUSTAFAR_META_EARLY) metab_ready(nxt); else metab_wait(nxt); \
+        cur = nxt;                                          \
+    }
+    MUSTAFAR_STEP(0) MUSTAFAR_STEP(1) MUSTAFAR_STEP(2)
+#undef MUSTAFAR_STEP
+    {
+        Gathered2 g;
+        uint64_t a0, a1;
+        gather8_d2(cur, adj, g);
+        coefm_issue_at<CBASE + 48>(ctab_lane, a0, a1);
+        gatherm_wait(g, a0, a1);
+        fma8_m2(g, a0, a1, acc);
+    }
+}
+
 // prefetch_meta without a divergent region (every lane loads; the lanes beyond the last sector repeat it): the lean kernels call it
 // inside their block loops, right in front of asm statements that own EXEC.  Tiles [T0, T0 + NT) of the block (a wave of the pair
 // form asks for its own half only), one 4-byte load per 64-byte line: NT / 8 lines of bitmaps, NT / 16 + 2 of offsets (the row may
@@ -1993,26 +2054,30 @@ template <int ENG, int TOFF, int COFF, int HS>
 __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
                                            const void* __restrict__ cbase, float (&acc)[4])
 {
+    // (with the coefficients in scalar registers as well, an early request leaves the loop 140+ registers short of the 78 a wave of
+    // this launch has, and the compiler then spills registers that loads are still writing: tools/check_smem_hazards.py)
+    constexpr bool kEarly = MUSTAFAR_META_EARLY > 1;
     MetaB cur, nxt;
     u32x4 c[4];
     metab_issue_at<TOFF>(cur, bmp_t, idx_t);
     coef4_issue_at<COFF, HS>(c, cbase);
     metab_wait(cur);
 #define MUSTAFAR_STEP(S)                                        \
+    if constexpr (kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t); \
     if constexpr (ENG == 2) {                                   \
         Gathered2 g;                                            \
         gather8_d2(cur, adj, g);                                \
         gather2_wait(g, c);                                     \
-        metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
+        if constexpr (!kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
         fma8_d2(c, g, acc);                                     \
     } else {                                                    \
         Gathered g;                                             \
         gather8(cur, adj, g);                                   \
         gather_wait<4>(g, c);                                   \
-        metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
+        if constexpr (!kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
         fma8<4>(c, g, acc);                                     \
     }                                                           \
-    metab_wait(nxt);                                            \
+    if constexpr (kEarly) metab_ready(nxt); else metab_wait(nxt); \
     coef4_issue_at<COFF + 16 * (S + 1), HS>(c, cbase);          \
     cur = nxt;
     MUSTAFAR_STEP(0) MUSTAFAR_STEP(1) MUSTAFAR_STEP(2)
@@ -2043,8 +2108,10 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
 #ifdef MUSTAFAR_WAVE_TRACE
                                                  , PhaseTrace& phase_trace_
 #endif
+                                                 , uint32_t ctab_lane = 0   // ENG == 1: the LDS coefficient table (cbase unused)
                                                  )
 {
+    f32x4 mA = {accA[0], accA[1], accA[2], accA[3]}, mB = {accB[0], accB[1], accB[2], accB[3]};   // (ENG == 1 only)
     uint32_t i0 = bnd_get(bnd, CB);
     const uint32_t len0 = 4u * (bnd_get(bnd, CB + 1) - i0);
     Stage st = stage_issue(nz_h + 4ull * i0, len0, lane);
@@ -2067,14 +2134,31 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
 #else
         const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
 #endif
-        if (c == 0)      chunk32_at<ENG, 0, 0, HS>(adj, bmp_t, idx_t, cbase, accA);
-        else if (c == 1) chunk32_at<ENG, 32, 64, HS>(adj, bmp_t, idx_t, cbase, accA);
-        else if (c == 2) chunk32_at<ENG, 64, VAL ? 0 : 128, HS>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
-        else             chunk32_at<ENG, 96, VAL ? 64 : 192, HS>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
+        if constexpr (ENG == 1) {
+            if (c == 0)      chunk32_mfma_at<0, 0>(adj, bmp_t, idx_t, ctab_lane, mA);
+            else if (c == 1) chunk32_mfma_at<32, 64>(adj, bmp_t, idx_t, ctab_lane, mA);
+            else if (c == 2) chunk32_mfma_at<64, VAL ? 0 : 128>(adj, bmp_t, idx_t, ctab_lane, VAL ? mB : mA);
+            else             chunk32_mfma_at<96, VAL ? 64 : 192>(adj, bmp_t, idx_t, ctab_lane, VAL ? mB : mA);
+        } else {
+            if (c == 0)      chunk32_at<ENG, 0, 0, HS>(adj, bmp_t, idx_t, cbase, accA);
+            else if (c == 1) chunk32_at<ENG, 32, 64, HS>(adj, bmp_t, idx_t, cbase, accA);
+            else if (c == 2) chunk32_at<ENG, 64, VAL ? 0 : 128, HS>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
+            else             chunk32_at<ENG, 96, VAL ? 64 : 192, HS>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
+        }
         __builtin_amdgcn_wave_barrier();
         if (c < CB + CN - 1) {
             stage_commit(lds, st, lane, nlen);
             i0 = n0;
+        }
+    }
+    if constexpr (ENG == 1) {   // (the pair form passes the same array for accA and accB: only the one its chunks went to is written)
+        if (CB < 2 || !VAL) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) accA[h] = mA[h];
+        }
+        if (VAL && CB + CN > 2) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) accB[h] = mB[h];
         }
     }
 }
@@ -2242,7 +2326,9 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     int64_t k_idx_stride, uint32_t k_nz_stride, int64_t v_bmp_stride, int64_t v_idx_stride, uint32_t v_nz_stride)
 {
     constexpr int G = 4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes];
+    // matrix-pipe engine: behind the stage windows, the q rows of the four heads ([4][kKeyTabStride]) and one e table per pair ([4][kValTabStride])
+    constexpr int kTabBytes = ENG == 1 ? 4 * kKeyTabStride + 2 * 4 * kValTabStride : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
     MUSTAFAR_PTRACE_BEGIN();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2279,6 +2365,18 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     float* xch = reinterpret_cast<float*>(smem + (2 * pair + 1) * kStageBytes);
     constexpr float kEScaleLog2 = ENG == 2 ? 15.f : 0.f;
 
+    uint32_t ctab_q = 0, ctab_e = 0;
+    unsigned char* ptab = nullptr;   // the pair's e table: e stays in LDS, no round trip through the score scratch
+    if constexpr (ENG == 1) {
+        unsigned char* tab = smem + kWaves * kStageBytes;
+        if (threadIdx.x < 64)
+            *reinterpret_cast<uint4*>(tab + (threadIdx.x >> 4) * kKeyTabStride + (threadIdx.x & 15) * 16) =
+                *reinterpret_cast<const uint4*>(qb + (int64_t)(threadIdx.x >> 4) * kD + (threadIdx.x & 15) * 8);
+        __syncthreads();
+        ptab = tab + 4 * kKeyTabStride + pair * (4 * kValTabStride);
+        ctab_q = (uint32_t)reinterpret_cast<uintptr_t>(tab) + (lane & 3) * kKeyTabStride;
+        ctab_e = (uint32_t)reinterpret_cast<uintptr_t>(ptab) + (lane & 3) * kValTabStride;
+    }
     float m_run[G], l_run[G], acc[G];   // acc: the wave's output half (even: channels 0..63, odd: 64..127); m_run, l_run live in the even wave
 #pragma unroll
     for (int h = 0; h < G; h++) { m_run[h] = -INFINITY; l_run[h] = 0.f; acc[h] = 0.f; }
@@ -2301,8 +2399,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
             const uint32_t bnd_k = bnd_load(kit, lane);
             const uint32_t pfk = odd ? prefetch_meta_all<64, 64>(kbt, kit, lane) : prefetch_meta_all<0, 64>(kbt, kit, lane);   // (the wave's own half)
             if (mrow) mk = mrow[tb * 64 + lane];
-            if (odd) lean_block_phase<ENG, kD * 2, false, 2, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG);
-            else     lean_block_phase<ENG, kD * 2, false, 0, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG);
+            if (odd) lean_block_phase<ENG, kD * 2, false, 2, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG, ctab_q);
+            else     lean_block_phase<ENG, kD * 2, false, 0, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG, ctab_q);
             prefetch_done(pfk);
             // the value side's chunk bounds and metadata lines are requested HERE, a barrier and a softmax step (~2 us) in front of
             // their use: requested at the block's start (~10 us ahead) the lines were often gone from L2 again by the time the
@@ -2324,7 +2422,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
                 const float m_new = uniform_f(fmaxf(m_run[h], wave_max(x)));
                 alpha[h] = uniform_f(__expf(m_run[h] - m_new));   // 0 for the first block (m_run = -inf)
                 const h16 e = (h16)__builtin_amdgcn_exp2f((x - m_new) * 1.44269504f + kEScaleLog2);
-                eblk[h * 64 + lane] = e;
+                if constexpr (ENG == 1) *reinterpret_cast<h16*>(ptab + h * kValTabStride + lane * 2) = e;
+                else                    eblk[h * 64 + lane] = e;
                 l_run[h] = uniform_f(l_run[h] * alpha[h] + wave_sum((float)e));
                 m_run[h] = m_new;
             }
@@ -2334,7 +2433,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
                 for (int h = 1; h < G; h++) mine = (lane == h) ? alpha[h] : mine;
                 xch[G * 64 + lane] = mine;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the e stores have reached L2 before the pair's scalar loads
+            if constexpr (ENG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the e stores have reached L2 before the pair's scalar loads
         }
         __syncthreads();
         MUSTAFAR_PTRACE_STAMP(3);
@@ -2346,8 +2445,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
 #pragma unroll
             for (int h = 0; h < G; h++) acc[h] *= alpha[h];
             // (the odd wave's LDS reads above are issued before its value phase rewrites the window: one wave, in order)
-            if (odd) lean_block_phase<ENG, 64 * 2, true, 2, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG);
-            else     lean_block_phase<ENG, 64 * 2, true, 0, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG);
+            if (odd) lean_block_phase<ENG, 64 * 2, true, 2, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
+            else     lean_block_phase<ENG, 64 * 2, true, 0, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
             prefetch_done(pfv);
         }
         MUSTAFAR_PTRACE_STAMP(5);
@@ -2738,7 +2837,8 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     // Structure by size (mode 2): the lean kernels (GQA-4, vector engines) and the matrix-pipe form run one-pass at every size
     // (round 3, tokens/s one-pass vs two launches -- dot2: c3 5110 vs 4180, c4 1540 vs 1350, c5 3470 vs 3130; fma_mix: c4 1416 vs
     // 1353, c5 3111 vs 3131); the round-2 pair form (G < 4) while kv-heads x T is small (c2: 1650 vs 1310)
-    const bool lean_form = G == 4 && fma_engine() != 1 && onepass_lean() != 0;
+    // (the matrix-pipe engine has the pair form only: lean == 1 keeps its round-2 whole-block kernel, as lean == 0 does)
+    const bool lean_form = G == 4 && onepass_lean() != 0 && !(fma_engine() == 1 && onepass_lean() == 1);
     const bool small = (int64_t)(Batch_Size / groups) * T <= 768000;
     if (T > 0 && onepass_enabled(Batch_Size / groups, T) && (onepass_mode() == 1 || lean_form || fma_engine() == 1 || small) &&
         (ld_scores & 31) == 0) {
@@ -2779,8 +2879,9 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                           vc.bmp, vz, vc.idx, vc.nz_offset, a, kc.bmp_head_stride, kc.idx_head_stride, (uint32_t)kc.nz_head_stride,    \
                           vc.bmp_head_stride, vc.idx_head_stride, (uint32_t)vc.nz_head_stride)
             if (lp) {
-                if (fma_engine() == 2) MUSTAFAR_LL((decode_onepass_leanpair_kernel<2>));
-                else                   MUSTAFAR_LL((decode_onepass_leanpair_kernel<0>));
+                if (fma_engine() == 2)      MUSTAFAR_LL((decode_onepass_leanpair_kernel<2>));
+                else if (fma_engine() == 1) MUSTAFAR_LL((decode_onepass_leanpair_kernel<1>));
+                else                        MUSTAFAR_LL((decode_onepass_leanpair_kernel<0>));
             } else {
                 if (fma_engine() == 2) MUSTAFAR_LL((decode_onepass_lean_kernel<2>));
                 else                   MUSTAFAR_LL((decode_onepass_lean_kernel<0>));
