@@ -1455,6 +1455,7 @@ struct OneArgs {   // operands of the one-pass launch beyond the two caches (by 
     MaskArg mask;
     int T, groups, BH, tb_per_wg, ld, w_len, w_cap, nchunks, win_rows;
     float inv_sqrt_d;
+    int pair_slabs = 0;    // pair form: every PAIR of waves leaves a slab of its own (2 per workgroup) instead of merging through LDS first
 };
 
 // Window workgroup: 64 window tokens of one head batch -> scores, softmax partial, p.V partial -> slab (S + chunk).
@@ -1810,7 +1811,10 @@ __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __rest
     const float* src = ws_o + (int64_t)bh * kD + c;
     // The first 64 slabs' outputs are requested BEFORE the weights are known: the loads fly while the maxima / sums are
     // loaded and reduced (the kernel is two dependent memory round trips otherwise; 36-68 slabs at c3).
-    constexpr int kEarly = 32;   // per thread: slabs par, par + 2, ..., par + 62
+#ifndef MUSTAFAR_FINISH_EARLY
+#define MUSTAFAR_FINISH_EARLY 32
+#endif
+    constexpr int kEarly = MUSTAFAR_FINISH_EARLY;   // per thread: slabs par, par + 2, ..., par + 2 * kEarly - 2 (128 slabs: a slab per pair at c3)
     float v[kEarly];
 #pragma unroll
     for (int i = 0; i < kEarly; i++) {
@@ -2336,7 +2340,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     const int wy = a.win_rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
     if (wy >= 0 && wy < wrows) {   // dense window
         const int task = wy * gridDim.x + blockIdx.x;
-        if (task < (int)(gridDim.y - wrows) * a.nchunks) onepass_window_wg<G>(smem, win_args(a), task, gridDim.x);
+        if (task < (int)(gridDim.y - wrows) * a.nchunks) onepass_window_wg<G>(smem, win_args(a), task, a.pair_slabs ? 2 * gridDim.x : gridDim.x);
         MUSTAFAR_PTRACE_END(5);
         return;
     }
@@ -2450,6 +2454,26 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
             prefetch_done(pfv);
         }
         MUSTAFAR_PTRACE_STAMP(5);
+    }
+    if (a.pair_slabs) {
+        // ---- a slab per pair: each wave stores its output half as it holds it, the even wave adds (maximum, sum) -- no exchange, no
+        // barrier; the row kernel folds twice as many slabs (c3: 126).  A pair without a block leaves a slab of weight zero.
+        constexpr float kOut = ENG == 2 ? 0x1p-15f : 1.f;   // the e scale leaves here (a power of two: exact)
+        const int64_t slab = (int64_t)blockIdx.x * 2 + pair;
+        float* so = a.ws_o + (slab * a.BH + bh0) * kD + (odd ? 64 : 0) + lane;
+#pragma unroll
+        for (int h = 0; h < G; h++) so[h * kD] = acc[h] * kOut;
+        if (!odd && lane < G) {
+            float mm = m_run[0], ll = l_run[0];
+#pragma unroll
+            for (int h = 1; h < G; h++) {
+                mm = (lane == h) ? m_run[h] : mm;
+                ll = (lane == h) ? l_run[h] : ll;
+            }
+            *reinterpret_cast<float2*>(a.ws_ml + (slab * a.BH + bh0 + lane) * 2) = make_float2(mm, ll * kOut);
+        }
+        MUSTAFAR_PTRACE_END(7);
+        return;
     }
     // ---- merge the two pairs: common maximum, rescaled sums and output halves -> one slab per head
     float* red = reinterpret_cast<float*>(smem);                 // [kWaves][G][64]
@@ -2566,6 +2590,7 @@ inline int onepass_target_wgs(bool pair)
 // GQA-4 one-pass launches on the vector engines: MUSTAFAR_ONEPASS_LEAN=2 (default) the lean kernel at the pair grain, 1 the lean
 // kernel with whole blocks per wave, 0 the round-2 pair form; MUSTAFAR_LEAN_TBW=n: blocks per wave (1) / block pairs per
 // workgroup (2) instead of the automatic choice (raised when the slabs would not fit).
+int g_pair_slabs = 0;   // pair form, mustafar_tune(4, 1): a slab per pair instead of one per workgroup (kernel 1.1 us shorter at c3, row kernel 1.5 us longer)
 int g_lean = -1, g_lean_tbw = -1, g_lean_win_last = 0;   // (window workgroups behind the SpMV rows: the launch 0.8 us shorter at c3, the step 1.5 % slower)
 inline int onepass_lean()
 {
@@ -2788,7 +2813,7 @@ int64_t mustafar_decode_workspace_bytes(int T, int Batch_Size, int num_key_value
     // (max, sum) pair per slab and row); sized for a slab per 64-token block (the forms in use leave at most one per two)
     const int ntb = T > 0 ? T / 64 : 1;
     const int sk = Split_K < 1 ? 1 : Split_K;
-    const int per_block = ntb < kMaxSlabs ? ntb : kMaxSlabs;
+    const int per_block = ntb + 1 < kMaxSlabs ? ntb + 1 : kMaxSlabs;   // (pair form: two slabs per workgroup of two blocks, the last one may hold one)
     const int slabs = sk > per_block ? sk : per_block;
     return (int64_t)(slabs + kMaxWindow / kOneWinChunk) * Batch_Size * (kD + 2) * (int64_t)sizeof(float);
 }
@@ -2864,13 +2889,15 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                 per_wg = kWaves * (onepass_lean_tbw() > 0 ? onepass_lean_tbw() : 1);
             }
             const int step = lp ? 2 : kWaves;
-            while ((ntb + per_wg - 1) / per_wg + nchunks > kMaxSlabs) per_wg += step;
-            const int S1 = (ntb + per_wg - 1) / per_wg;
+            const int spw = lp && g_pair_slabs ? 2 : 1;   // slabs per workgroup
+            while (spw * ((ntb + per_wg - 1) / per_wg) + nchunks > kMaxSlabs) per_wg += step;
+            const int S1 = (ntb + per_wg - 1) / per_wg;   // workgroups per head group
+            const int NS = spw * S1;                      // their slabs
             float* ws_o = static_cast<float*>(workspace);
-            float* ws_ml = ws_o + (int64_t)(S1 + nchunks) * Batch_Size * kD;
+            float* ws_ml = ws_o + (int64_t)(NS + nchunks) * Batch_Size * kD;
             const int win_rows = (gy * nchunks + S1 - 1) / S1;
             const OneArgs a{qh, sc, ws_o, ws_ml, kwin, vwin, knew, vnew, window_len_extra, mask, T, groups, Batch_Size, lp ? per_wg : per_wg / kWaves,
-                            ld_scores, window_len, window_capacity, nchunks, g_lean_win_last ? -win_rows : win_rows, inv_sqrt_d0};
+                            ld_scores, window_len, window_capacity, nchunks, g_lean_win_last ? -win_rows : win_rows, inv_sqrt_d0, spw == 2};
             const dim3 grid(S1, gy + win_rows);
             hipEvent_t e0 = prof ? g_prof.ev[4 * g_prof.n] : nullptr, e1 = prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr;
             auto kz = static_cast<const unsigned char*>(kc.nz), vz = static_cast<const unsigned char*>(vc.nz);
@@ -2888,7 +2915,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             }
 #undef MUSTAFAR_LL
             if (prof) { g_prof.onepass++; g_prof.n++; }
-            onepass_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, S1 + nchunks, static_cast<h16*>(out), Batch_Size);
+            onepass_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
             t_last_choice = fma_engine() | (1 << 4) | ((lp ? 2 : 1) << 8);
             return (int)hipGetLastError();
         }
@@ -3106,6 +3133,7 @@ int mustafar_tune(int knob, int value)
         case 1: g_lean_tbw = value; return 0;
         case 2: g_onepass_wgs = value; return 0;
         case 3: g_lean_win_last = value ? 1 : 0; return 0;
+        case 4: g_pair_slabs = value ? 1 : 0; return 0;
         default: return MUSTAFAR_EINVAL;
     }
 }
