@@ -284,8 +284,8 @@ class Workload:
         box = {"g": None, "since": 0, "triggers": 0, "next": None}
 
         def signature(st):   # addresses a captured graph holds: a re-housed arena or window makes the graph stale
-            return tuple((p[0].bmp.data_ptr(), p[0].nz.data_ptr(), p[0].idx.data_ptr(), p[2].bmp.data_ptr(), p[2].nz.data_ptr(), p[2].idx.data_ptr(),
-                          p[1].buf.data_ptr(), p[3].buf.data_ptr(), p[1].len, p[3].len, p[4], p[5]) for p in st)
+            # (a cache that grows by extents keeps its base arrays and its extent table where they are: cache.py)
+            return tuple((p[0].signature(), p[2].signature(), p[1].buf.data_ptr(), p[3].buf.data_ptr(), p[1].len, p[3].len, p[4], p[5]) for p in st)
 
         pool = torch.cuda.graph_pool_handle()   # one memory pool for every graph of this leg: a capture behind a trigger then finds
                                                 # the blocks of the graph it replaces instead of asking the driver for new ones (16 ms -> 0.7 ms)

@@ -148,6 +148,24 @@ typedef struct mustafar_cache_view {
                                    the head's stream start instead of loading it (one memory latency less per wave) */
 } mustafar_cache_view;
 
+/*
+ * mustafar_decode_attention over a cache that GROWS BY EXTENTS (the 256-token trigger of models/llama_mustafar_kernel.py:324-398
+ * without copying or moving what is already compressed): tokens [0, T_base) live in the two base views, tokens
+ * [T_base + 256 i, T_base + 256 (i + 1)) in entry i of `k_extents` / `v_extents` -- arrays of mustafar_cache_view in DEVICE memory,
+ * each describing a 256-token cache of its own (offsets relative to that extent; nz_head_stride != 0).  An entry is written once,
+ * before the first call that names it, and never changed: a captured hipGraph of a call stays valid while the cache grows
+ * behind it.  T_base and T - T_base are multiples of 256.  Read by the pair form of the one-pass launch (GQA groups % 4 == 0,
+ * ld_scores % 32 == 0; mustafar_decode_reads_extents() tells); MUSTAFAR_EINVAL otherwise -- consolidate into one view then.
+ */
+int mustafar_decode_attention_extents(void* stream, const mustafar_cache_view* k_base, const mustafar_cache_view* v_base, int T_base,
+                                      const mustafar_cache_view* k_extents, const mustafar_cache_view* v_extents,
+                                      const void* q, void* k_window, void* v_window, const void* k_new, const void* v_new,
+                                      int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
+                                      int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
+                                      const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
+                                      int heads_per_mask_row, uint32_t flags);
+int mustafar_decode_reads_extents(int num_key_value_groups, int ld_scores, uint32_t flags);
+
 /* mustafar_decode_attention over two cache views (same semantics, same remaining arguments). */
 int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_cache, const mustafar_cache_view* v_cache,
                                    const void* q, void* k_window, void* v_window, const void* k_new, const void* v_new,

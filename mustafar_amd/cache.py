@@ -23,6 +23,16 @@ is reserved for a worst-case append any more:
     asynchronous, as in round 2: lengths and flag then travel through pinned memory and are looked at on the next use.
 Bit 1 of the flag (a block of the one-pass compression gave up waiting for the lengths in front of it: it relies on lower
 workgroup ids being dispatched first) is a hard error with its own exception; it is never answered by a retry.
+
+Growth by extents (round 3b).  Re-housing copies the whole cache, and at 8 k tokens a 3 % margin is smaller than one trigger: every
+trigger paid one copy of the cache, a round of driver allocations and -- because every array moved -- a new capture of the decode
+graph (c3: 16 + 11 ms per trigger against 1.4 ms per step).  `append_extent_pair` instead compresses the 256 tokens of a trigger into
+a small arena of their own, an EXTENT, and lists its view in a device table next to the base arena (`ext_table`).  Nothing that is
+already compressed is read, written or moved; the pair form of the one-pass decode launch takes the blocks behind the base tokens
+from the table (mustafar_decode_attention_extents), so the base pointers, the table pointer and therefore a graph captured ahead
+stay valid across the trigger.  `tokens` / the four arrays keep describing the BASE; `total_tokens` counts the extents too,
+`to_reference()` concatenates, and after `MAX_EXTENTS` triggers (or when a launch form that cannot read extents is asked for)
+`consolidate()` re-houses everything into one base again.
 """
 from __future__ import annotations
 
@@ -57,11 +67,15 @@ def _cap_nz(halfs: int, slack: float) -> int:
 
 class CompressedArena:
     TILES_PER_TOKEN = 2   # head_dim 128 / 64
+    MAX_EXTENTS = 64      # appended 256-token extents listed in the device table (16 k tokens of generation) before a consolidation
+    VIEW_BYTES = ctypes.sizeof(_lib.CacheView)
 
     def __init__(self, heads: int, which: str, device, cap_tokens: int, nz_cap: int, slack: float = DEFAULT_SLACK):
         assert which in ("key", "value") and cap_tokens % 64 == 0 and nz_cap % 8 == 0
         self.heads, self.which, self.device, self.slack = heads, which, device, slack
         self.tokens = 0
+        self.extents: List["CompressedArena"] = []   # appended 256-token extents, oldest first (module docstring)
+        self._ext_table = None                        # device copy of their views (MAX_EXTENTS x mustafar_cache_view)
         self._alloc(cap_tokens, nz_cap)
         self._init_empty()
 
@@ -146,10 +160,53 @@ class CompressedArena:
 
     def bytes_in_use(self) -> int:
         t = self.tokens * self.TILES_PER_TOKEN
-        return self.heads * (t * 8 + (t + 1) * 4 + 4) + int(self.used.sum()) * 2
+        return self.heads * (t * 8 + (t + 1) * 4 + 4) + int(self.used.sum()) * 2 + sum(e.bytes_in_use() for e in self.extents)
 
     def bytes_reserved(self) -> int:
-        return sum(x.numel() * x.element_size() for x in (self.bmp, self.idx, self.nz, self.nz_offset))
+        own = sum(x.numel() * x.element_size() for x in (self.bmp, self.idx, self.nz, self.nz_offset))
+        return own + sum(e.bytes_reserved() for e in self.extents) + (self._ext_table.numel() if self._ext_table is not None else 0)
+
+    # ---- growth by extents (module docstring) ------------------------------------------------------------------
+    @property
+    def total_tokens(self) -> int:
+        return self.tokens + 256 * len(self.extents)
+
+    @property
+    def ext_table(self) -> torch.Tensor:
+        """Device table of the extents' views; created on first use (a decode graph captured AHEAD of a trigger names it before
+        the first extent exists)."""
+        if self._ext_table is None:
+            self._ext_table = torch.zeros(self.MAX_EXTENTS * self.VIEW_BYTES, dtype=torch.uint8, device=self.device)
+        return self._ext_table
+
+    def signature(self) -> tuple:
+        """Addresses a captured decode graph holds for this cache (extents are found through the table at run time)."""
+        return (self.bmp.data_ptr(), self.nz.data_ptr(), self.idx.data_ptr(), self.tokens, self.ext_table.data_ptr())
+
+    def _list_extent(self, ext: "CompressedArena") -> None:
+        i = len(self.extents)
+        raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.byref(ext._view), self.VIEW_BYTES)), dtype=torch.uint8)
+        self.ext_table[i * self.VIEW_BYTES:(i + 1) * self.VIEW_BYTES].copy_(raw)   # (stream-ordered: in front of every later launch)
+        self.extents.append(ext)
+
+    @staticmethod
+    def append_extent_pair(k_arena: "CompressedArena", v_arena: "CompressedArena", k_rows: torch.Tensor, v_rows: torch.Tensor,
+                           kth_k: int, kth_v: int) -> None:
+        """The 256-token trigger without touching what is compressed already: rows [0, 256) of the window buffers become an extent
+        of each side (prune + compress in one launch: from_raw_pair), listed in the device tables."""
+        if len(k_arena.extents) >= k_arena.MAX_EXTENTS or len(k_arena.extents) != len(v_arena.extents) or k_arena.tokens % 256:
+            raise RuntimeError("append_extent_pair: extent table full (consolidate() first) or K / V out of step")
+        ek, ev = CompressedArena.from_raw_pair(k_rows, v_rows, 256, kth_k, kth_v, None, k_arena.slack)
+        if ek._view.nz_head_stride == 0 or ev._view.nz_head_stride == 0:
+            raise RuntimeError("append_extent_pair: extents need views with a stream stride")
+        k_arena._list_extent(ek)
+        v_arena._list_extent(ev)
+
+    def consolidate(self) -> "CompressedArena":
+        """One base arena holding everything (a copy of the cache; the addresses of the result are new)."""
+        if not self.extents:
+            return self
+        return CompressedArena.from_reference(self.to_reference(), self.which, self.total_tokens, None, self.slack)
 
     def _rehouse(self, cap_tokens: int, nz_cap: int):
         """Move the cache into rows of `cap_tokens` tokens and stream regions of `nz_cap` halfs (never below what it holds):
@@ -247,6 +304,8 @@ class CompressedArena:
         heads = k_arena.heads
         if v_arena.heads != heads or k_arena.tokens != v_arena.tokens or t % 64 or t <= 0:
             raise RuntimeError("append_window_pair: K and V arenas must describe the same heads and tokens; t % 64 == 0")
+        if k_arena.extents or v_arena.extents:
+            raise RuntimeError("append_window_pair: the cache has grown by extents; append_extent_pair() or consolidate()")
         for x in (k_rows, v_rows):
             if x.dtype != torch.float16 or x.dim() != 4 or x.shape[0] * x.shape[1] != heads or x.shape[3] != 128 or x.shape[2] < t \
                     or not x.is_contiguous():
@@ -369,6 +428,17 @@ class CompressedArena:
 
     def to_reference(self) -> list:
         """[bitmaps int64 [B', 2T], idxs int32 [B', 2T+1], list of B' fp16 streams, nz_offset] (contiguous copies)."""
+        from .hook import append_compressed
+        base = self._base_reference()
+        if not self.extents:
+            return base
+        tokens = self.tokens   # base + extents, concatenated the way the model appends (llama_mustafar_kernel.py:339-390)
+        for e in self.extents:
+            base = append_compressed(base, e._base_reference(), self.heads, tokens, 256, 128)
+            tokens += 256
+        return [base[0].view(self.heads, -1), base[1].view(self.heads, -1), base[2], base[3]]
+
+    def _base_reference(self) -> list:
         from .compression import pieces_of
         from .hook import FlatStreams, nz_offset_from_idxs
         t = self.tokens * self.TILES_PER_TOKEN
@@ -382,3 +452,4 @@ class CompressedArena:
         for h, u in enumerate(used):
             flat[offs[h]:offs[h + 1]] = self.nz[h, :u]
         return [bmp, idx, FlatStreams(pieces_of(flat, offs)), nz_offset_from_idxs(idx, self.heads)]
+

@@ -1456,6 +1456,11 @@ struct OneArgs {   // operands of the one-pass launch beyond the two caches (by 
     int T, groups, BH, tb_per_wg, ld, w_len, w_cap, nchunks, win_rows;
     float inv_sqrt_d;
     int pair_slabs = 0;    // pair form: every PAIR of waves leaves a slab of its own (2 per workgroup) instead of merging through LDS first
+    // appended extents (pair form): blocks [0, nb0) live in the views the launch carries, block nb0 + 4 i + j in entry i of these
+    // DEVICE tables (a 256-token cache of its own each: mustafar_decode_attention_extents); nullptr: one extent
+    const mustafar_cache_view* k_ext = nullptr;
+    const mustafar_cache_view* v_ext = nullptr;
+    int nb0 = 0;
 };
 
 // Window workgroup: 64 window tokens of one head batch -> scores, softmax partial, p.V partial -> slab (S + chunk).
@@ -2353,13 +2358,34 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     const int tb_end = min(ntb, tb0 + a.tb_per_wg);
     const int pair = wave >> 1;
     const bool odd = wave & 1;
-    const int64_t tiles = (int64_t)ntb * kTilesPerTb;
-    const uint64_t* kb = k_bmp + (int64_t)kvh * (k_bmp_stride ? k_bmp_stride : tiles);
-    const uint32_t* ki = k_idx + (int64_t)kvh * (k_idx_stride ? k_idx_stride : tiles + 1);
-    const unsigned char* kn = k_nz + 16ull * (k_nz_stride ? (uint64_t)kvh * k_nz_stride : (uint64_t)k_nz_off[kvh]);
-    const uint64_t* vb = v_bmp + (int64_t)kvh * (v_bmp_stride ? v_bmp_stride : tiles);
-    const uint32_t* vi = v_idx + (int64_t)kvh * (v_idx_stride ? v_idx_stride : tiles + 1);
-    const unsigned char* vn = v_nz + 16ull * (v_nz_stride ? (uint64_t)kvh * v_nz_stride : (uint64_t)v_nz_off[kvh]);
+    const int64_t tiles = (int64_t)(a.k_ext ? a.nb0 : ntb) * kTilesPerTb;
+    const uint64_t* kb;
+    const uint32_t* ki;
+    const unsigned char* kn;
+    const uint64_t* vb;
+    const uint32_t* vi;
+    const unsigned char* vn;
+    if (a.k_ext && tb0 >= a.nb0) {
+        // a workgroup of an appended extent (its blocks never straddle two: extents are four blocks, workgroups two or four):
+        // the extent's arrays, biased so that the block loop's `+ tb * 128` lands inside them.  One more scalar round trip than
+        // the base extent's workgroups, whose pointers arrive with the launch.
+        const int e = (tb0 - a.nb0) >> 2;
+        const mustafar_cache_view ek = a.k_ext[e], ev = a.v_ext[e];
+        const int64_t t0 = (int64_t)(a.nb0 + 4 * e) * kTilesPerTb;
+        kb = ek.bmp + (int64_t)kvh * ek.bmp_head_stride - t0;
+        ki = ek.idx + (int64_t)kvh * ek.idx_head_stride - t0;
+        kn = static_cast<const unsigned char*>(ek.nz) + 16ull * (uint64_t)kvh * (uint64_t)ek.nz_head_stride;
+        vb = ev.bmp + (int64_t)kvh * ev.bmp_head_stride - t0;
+        vi = ev.idx + (int64_t)kvh * ev.idx_head_stride - t0;
+        vn = static_cast<const unsigned char*>(ev.nz) + 16ull * (uint64_t)kvh * (uint64_t)ev.nz_head_stride;
+    } else {
+        kb = k_bmp + (int64_t)kvh * (k_bmp_stride ? k_bmp_stride : tiles);
+        ki = k_idx + (int64_t)kvh * (k_idx_stride ? k_idx_stride : tiles + 1);
+        kn = k_nz + 16ull * (k_nz_stride ? (uint64_t)kvh * k_nz_stride : (uint64_t)k_nz_off[kvh]);
+        vb = v_bmp + (int64_t)kvh * (v_bmp_stride ? v_bmp_stride : tiles);
+        vi = v_idx + (int64_t)kvh * (v_idx_stride ? v_idx_stride : tiles + 1);
+        vn = v_nz + 16ull * (v_nz_stride ? (uint64_t)kvh * v_nz_stride : (uint64_t)v_nz_off[kvh]);
+    }
     const h16* qb = a.q + (int64_t)bh0 * kD;
     h16* eb = a.e_rows + (int64_t)by * ntb * (G * 64);
     const h16* mrow = a.mask.ptr ? a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride : nullptr;
@@ -2825,9 +2851,11 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                      void* v_window, const void* k_new, const void* v_new, int window_len, int window_capacity, void* scores,
                      int ld_scores, void* out, void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups,
                      float sqrt_d, const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
-                     int heads_per_mask_row, uint32_t flags)
+                     int heads_per_mask_row, uint32_t flags, const mustafar_cache_view* k_ext = nullptr,
+                     const mustafar_cache_view* v_ext = nullptr, int T_base = 0)
 {
     const int groups = num_key_value_groups;
+    const bool extents = k_ext != nullptr;   // (validated by mustafar_decode_attention_extents)
     // the call's own engine / structure (mustafar_hip.h: MUSTAFAR_FLAG_*), in force until this function returns
     const uint32_t f_eng = flags & 7u, f_str = (flags >> 4) & 3u;
     if (f_eng > 3u || f_str > 2u || (flags & ~0x37u)) return MUSTAFAR_EINVAL;
@@ -2843,7 +2871,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
         return MUSTAFAR_EINVAL;
     if (!q || !k_window || !v_window || !scores || !out || !workspace) return MUSTAFAR_EINVAL;
     if (T > 0 && (!kc.bmp || !kc.nz || !kc.idx || !kc.nz_offset || !vc.bmp || !vc.nz || !vc.idx || !vc.nz_offset)) return MUSTAFAR_EINVAL;
-    const int64_t tiles = (int64_t)T * 2;
+    const int64_t tiles = (int64_t)(extents ? T_base : T) * 2;   // (the base views hold T_base of the T tokens when the cache grew by extents)
     if (T > 0 && ((kc.bmp_head_stride && kc.bmp_head_stride < tiles) || (kc.idx_head_stride && kc.idx_head_stride < tiles + 1) ||
                   (vc.bmp_head_stride && vc.bmp_head_stride < tiles) || (vc.idx_head_stride && vc.idx_head_stride < tiles + 1)))
         return MUSTAFAR_EINVAL;
@@ -2865,6 +2893,9 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     // (the matrix-pipe engine has the pair form only: lean == 1 keeps its round-2 whole-block kernel, as lean == 0 does)
     const bool lean_form = G == 4 && onepass_lean() != 0 && !(fma_engine() == 1 && onepass_lean() == 1);
     const bool small = (int64_t)(Batch_Size / groups) * T <= 768000;
+    // appended extents are read by the pair form of the one-pass launch only
+    if (extents && !(T > 0 && lean_form && onepass_lean() == 2 && onepass_enabled(Batch_Size / groups, T) && (ld_scores & 31) == 0))
+        return MUSTAFAR_EINVAL;
     if (T > 0 && onepass_enabled(Batch_Size / groups, T) && (onepass_mode() == 1 || lean_form || fma_engine() == 1 || small) &&
         (ld_scores & 31) == 0) {
         // ---- one-pass form: every wave runs key phase -> softmax step -> value phase on its token blocks; slabs merged per row
@@ -2896,8 +2927,14 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             float* ws_o = static_cast<float*>(workspace);
             float* ws_ml = ws_o + (int64_t)(NS + nchunks) * Batch_Size * kD;
             const int win_rows = (gy * nchunks + S1 - 1) / S1;
-            const OneArgs a{qh, sc, ws_o, ws_ml, kwin, vwin, knew, vnew, window_len_extra, mask, T, groups, Batch_Size, lp ? per_wg : per_wg / kWaves,
-                            ld_scores, window_len, window_capacity, nchunks, g_lean_win_last ? -win_rows : win_rows, inv_sqrt_d0, spw == 2};
+            if (extents && (!lp || (per_wg != 2 && per_wg != 4))) return MUSTAFAR_EINVAL;   // a workgroup's blocks stay inside one extent
+            OneArgs a{qh, sc, ws_o, ws_ml, kwin, vwin, knew, vnew, window_len_extra, mask, T, groups, Batch_Size, lp ? per_wg : per_wg / kWaves,
+                      ld_scores, window_len, window_capacity, nchunks, g_lean_win_last ? -win_rows : win_rows, inv_sqrt_d0, spw == 2};
+            if (extents) {
+                a.k_ext = k_ext;
+                a.v_ext = v_ext;
+                a.nb0 = T_base / 64;
+            }
             const dim3 grid(S1, gy + win_rows);
             hipEvent_t e0 = prof ? g_prof.ev[4 * g_prof.n] : nullptr, e1 = prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr;
             auto kz = static_cast<const unsigned char*>(kc.nz), vz = static_cast<const unsigned char*>(vc.nz);
@@ -3049,6 +3086,34 @@ int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_ca
     return decode_attention(stream, k_cache ? *k_cache : none, v_cache ? *v_cache : none, q, k_window, v_window, k_new, v_new,
                             window_len, window_capacity, scores, ld_scores, out, workspace, Split_K, T, Batch_Size,
                             num_key_value_groups, sqrt_d, window_len_extra, attention_mask, mask_row_stride, heads_per_mask_row, flags);
+}
+
+int mustafar_decode_attention_extents(void* stream, const mustafar_cache_view* k_base, const mustafar_cache_view* v_base, int T_base,
+                                      const mustafar_cache_view* k_extents, const mustafar_cache_view* v_extents,
+                                      const void* q, void* k_window, void* v_window, const void* k_new, const void* v_new,
+                                      int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
+                                      int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
+                                      const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
+                                      int heads_per_mask_row, uint32_t flags)
+{
+    if (!k_base || !v_base || T_base <= 0 || (T_base & 255) || T < T_base || ((T - T_base) & 255)) return MUSTAFAR_EINVAL;
+    if (T == T_base)   // no appended extent: the plain call
+        return decode_attention(stream, *k_base, *v_base, q, k_window, v_window, k_new, v_new, window_len, window_capacity, scores, ld_scores,
+                                out, workspace, Split_K, T, Batch_Size, num_key_value_groups, sqrt_d, window_len_extra, attention_mask,
+                                mask_row_stride, heads_per_mask_row, flags);
+    if (!k_extents || !v_extents || k_base->nz_head_stride == 0 || v_base->nz_head_stride == 0) return MUSTAFAR_EINVAL;
+    return decode_attention(stream, *k_base, *v_base, q, k_window, v_window, k_new, v_new, window_len, window_capacity, scores, ld_scores,
+                            out, workspace, Split_K, T, Batch_Size, num_key_value_groups, sqrt_d, window_len_extra, attention_mask,
+                            mask_row_stride, heads_per_mask_row, flags, k_extents, v_extents, T_base);
+}
+
+int mustafar_decode_reads_extents(int num_key_value_groups, int ld_scores, uint32_t flags)
+{
+    const uint32_t f_eng = flags & 7u, f_str = (flags >> 4) & 3u;
+    if (f_eng > 3u || f_str > 2u || (flags & ~0x37u)) return 0;
+    if (f_str == 1u || (f_str == 0u && onepass_mode() == 0)) return 0;   // two launches asked for (by the call or by the process default)
+    return pick_g(num_key_value_groups) == 4 && onepass_lean() == 2 && (ld_scores & 31) == 0 && g_onepass_wgs <= 0 &&
+           (onepass_lean_tbw() == 0 || onepass_lean_tbw() == 1 || onepass_lean_tbw() == 2);
 }
 
 int mustafar_profile_begin(int max_records)

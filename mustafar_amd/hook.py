@@ -43,6 +43,8 @@ class MustafarConfig:
     group_size: int = 32          # carried by the reference config, unused on the kernel path
     api: str = "native"           # "reference" | "native" | "fused"
     arena: bool = False           # api="fused": keep the compressed cache in CompressedArena objects (in-place append)
+    extents: bool = True          # arena: a 256-token trigger adds an extent instead of re-housing the cache (cache.py), where the
+                                  # decode launch can read extents (GQA groups % 4 == 0, one-pass pair form)
     arena_slack: float = 0.03       # an arena is housed at (1 + arena_slack) x the rows / stream bytes it holds (cache.py: DEFAULT_SLACK)
     # api="fused": this instance's FMA engine ("dot2" | "valu" | "mfma"; None = the process default) and launch structure
     # ("one_pass" | "two_launch"; None = by size).  Carried in every call's `flags` (include/mustafar_hip.h): two instances in
@@ -313,13 +315,22 @@ class MustafarAttention:
         if use_arena:            # a failed asynchronous append is reported before the cache is read again (no host stall)
             k_c.poll()
             v_c.poll()
+            if cfg.extents and k_c._ext_table is None and not torch.cuda.is_current_stream_capturing():
+                k_c.ext_table, v_c.ext_table   # (the extent tables exist before a graph that names them is captured)
         tail = (q.data_ptr(), k_w.buf.data_ptr(), v_w.buf.data_ptr(), kn.data_ptr(), vn.data_ptr(), w_len, k_w.cap,
                 scores.data_ptr(), ld, out.data_ptr(), ws.data_ptr(), split, C, BH, groups, math.sqrt(D),
                 step_counter.data_ptr() if step_counter is not None else None, mask_ptr, mask_stride, self.num_heads,
                 _lib.ENGINE_FLAGS[cfg.engine] | _lib.STRUCTURE_FLAGS[cfg.structure])
+        flags = tail[-1]
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
-            if use_arena:
+            if use_arena and C > k_c.tokens:
+                # the cache has grown by extents (or, under a capture ahead of a trigger, is about to): base views + device tables
+                if not L.mustafar_decode_reads_extents(groups, ld, flags):
+                    raise RuntimeError("decode_fused: this launch form cannot read a cache that grew by extents; consolidate() it")
+                err = L.mustafar_decode_attention_extents(st, k_c.view_ptr(), v_c.view_ptr(), k_c.tokens, k_c.ext_table.data_ptr(),
+                                                          v_c.ext_table.data_ptr(), *tail)
+            elif use_arena:
                 err = L.mustafar_decode_attention_view(st, k_c.view_ptr(), v_c.view_ptr(), *tail)
             else:
                 err = L.mustafar_decode_attention(
@@ -336,7 +347,13 @@ class MustafarAttention:
                 # prune (:325-326) + compress + append (:328-390) of the raw window rows in one launch, no host read
                 if C == 0:
                     k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, None, cfg.arena_slack)
+                elif cfg.extents and k_c.tokens % 256 == 0 and L.mustafar_decode_reads_extents(groups, ld, flags):
+                    if len(k_c.extents) >= k_c.MAX_EXTENTS:          # table full: one copy of the cache, then extents again
+                        k_c, v_c = k_c.consolidate(), v_c.consolidate()
+                    CompressedArena.append_extent_pair(k_c, v_c, k_w.buf, v_w.buf, kth_k, kth_v)
                 else:
+                    if k_c.extents:
+                        k_c, v_c = k_c.consolidate(), v_c.consolidate()
                     CompressedArena.append_window_pair(k_c, v_c, k_w.buf, v_w.buf, 256, kth_k, kth_v)
                 Window.drop_front_pair(k_w, v_w, 256)                                                   # :392-393, in place
             else:

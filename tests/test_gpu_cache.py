@@ -101,7 +101,7 @@ def test_decode_through_arena_is_bit_identical(hq, hkv):
             o, pasts[i] = attns[i].decode(qn, kn, vn, pasts[i])
             outs.append(o)
         assert torch.equal(outs[0], outs[1]), f"step {step}"
-    assert pasts[0][4] == pasts[1][4] == 512 and pasts[1][0].tokens == 512
+    assert pasts[0][4] == pasts[1][4] == 512 and pasts[1][0].total_tokens == 512
     ref = pasts[1][0].to_reference()
     assert torch.equal(ref[0].flatten(), pasts[0][0][0].flatten()) and torch.equal(ref[1].flatten(), pasts[0][0][1].flatten())
 

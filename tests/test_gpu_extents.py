@@ -1,0 +1,140 @@
+"""GPU: growth of the compressed cache by extents (mustafar_amd/cache.py, mustafar_decode_attention_extents).
+
+The 256-token trigger of models/llama_mustafar_kernel.py:324-398 appends to the compressed cache; the reference re-copies the cache
+to do so.  With `MustafarConfig.extents` the trigger compresses its 256 tokens into an extent of their own and lists it in a device
+table; the pair form of the one-pass launch reads the blocks behind the base tokens through that table.  Held here:
+  * the same decode sequence through several triggers with extents and with the in-place append gives the SAME outputs (bit for
+    bit: the same blocks, the same workgroups, the same slabs) and the same cache in the reference layout, and both equal dense
+    fp32 attention over oracle-pruned K / V;
+  * nothing a captured graph holds moves: base arrays, extent table and windows keep their addresses across a trigger, and a graph
+    of the step BEHIND a trigger, captured before it, replays correctly after it;
+  * a full table is answered by one consolidation, a launch form that cannot read extents by the in-place append.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+R = 32
+
+
+def _attn(hq, hkv, **kw):
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    return MustafarAttention(MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, k_sparsity=0.7, v_sparsity=0.7,
+                                            api="fused", arena=True, **kw))
+
+
+def _dense(q, K_all, V_all, C, s, groups):
+    K, V = K_all.clone(), V_all.clone()
+    K[:, :, :C] = torch.from_numpy(orc.prune_magnitude(K_all[:, :, :C].cpu().numpy(), s)).to(K.device)
+    V[:, :, :C] = torch.from_numpy(orc.prune_magnitude(V_all[:, :, :C].cpu().numpy(), s)).to(V.device)
+    Kr = K.double().repeat_interleave(groups, dim=1)
+    Vr = V.double().repeat_interleave(groups, dim=1)
+    sc = torch.matmul(q.double(), Kr.transpose(2, 3)) / math.sqrt(q.shape[-1])
+    return torch.matmul(torch.softmax(sc, -1), Vr).float()
+
+
+def _run(attn, K0, V0, qs, ks, vs):
+    past = attn.to_fused(attn.build_cache(K0.clone(), V0.clone()))
+    outs = []
+    for q, k, v in zip(qs, ks, vs):
+        out, past = attn.decode(q, k, v, past)
+        outs.append(out)
+    return outs, past
+
+
+@pytest.mark.parametrize("engine", ["dot2", "valu", "mfma"])
+def test_extents_equal_in_place_append_and_dense_through_three_triggers(engine):
+    torch.manual_seed(5)
+    bsz, hq, hkv, D = 2, 8, 2, 128
+    L0, steps = 512 + R + 200, 56 + 2 * 256 + 9               # first trigger after 56 steps, then two more
+    K0, V0 = (torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(2))
+    qs = [torch.randn(bsz, hq, 1, D, device=DEV).half() for _ in range(steps)]
+    ks = [torch.randn(bsz, hkv, 1, D, device=DEV).half() for _ in range(steps)]
+    vs = [torch.randn(bsz, hkv, 1, D, device=DEV).half() for _ in range(steps)]
+    o_ext, p_ext = _run(_attn(hq, hkv, engine=engine, extents=True), K0, V0, qs, ks, vs)
+    o_inp, p_inp = _run(_attn(hq, hkv, engine=engine, extents=False), K0, V0, qs, ks, vs)
+    assert len(p_ext[0].extents) == 3 and len(p_ext[2].extents) == 3 and not p_inp[0].extents
+    assert p_ext[0].tokens == 512 and p_ext[0].total_tokens == p_ext[4] == p_inp[4] == p_inp[0].tokens == 1280
+    for i, (a, b) in enumerate(zip(o_ext, o_inp)):
+        assert torch.equal(a, b), f"step {i}: extents and in-place append differ"
+    for side in (0, 2):                                        # the caches, in the reference layout
+        a, b = p_ext[side].to_reference(), p_inp[side].to_reference()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+        assert torch.equal(torch.cat(list(a[2])), torch.cat(list(b[2])))
+    K_all = torch.cat([K0] + ks, 2)
+    V_all = torch.cat([V0] + vs, 2)
+    want = _dense(qs[-1], K_all, V_all, 1280, 0.7, hq // hkv)
+    torch.testing.assert_close(o_ext[-1].float(), want, rtol=4e-3, atol=2e-3)
+    # the extents cost what they hold: a few per cent over the bytes in use, nothing re-housed
+    assert p_ext[0].bytes_reserved() <= p_ext[0].bytes_in_use() * 1.06 + 4096 * p_ext[0].heads
+
+
+def test_addresses_survive_a_trigger_and_a_graph_captured_ahead_replays_behind_it():
+    from mustafar_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(6)
+    bsz, hq, hkv, D = 2, 8, 2, 128
+    L0 = 768 + R + 250                                         # the trigger fires at the 6th decode step
+    K0, V0 = (torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(2))
+    attn = _attn(hq, hkv)
+    past = attn.to_fused(attn.build_cache(K0.clone(), V0.clone()))
+    hist_k, hist_v = [K0], [V0]
+    def new():
+        return tuple(torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+    for _ in range(3):
+        q, k, v = new()
+        _, past = attn.decode(q, k, v, past)
+        hist_k.append(k); hist_v.append(v)
+    sig = (past[0].signature(), past[2].signature(), past[1].buf.data_ptr(), past[3].buf.data_ptr())
+    # the graph of the first step BEHIND the trigger, captured three steps before it fires: 256 more compressed tokens, windows at R rows
+    import copy
+    kw, vw = copy.copy(past[1]), copy.copy(past[3])
+    kw.len = vw.len = R
+    fut = (past[0], kw, past[2], vw, past[4] + 256, past[5] + 3)
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    gq, gk, gv = new()
+    attn.decode_fused(gq, gk, gv, (past[0], past[1].clone(), past[2], past[3].clone(), past[4], past[5]))   # scratch outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        g_out, _ = attn.decode_fused(gq, gk, gv, fut, step_counter=counter)
+    for _ in range(3):                                         # ... the trigger fires in the third of these
+        q, k, v = new()
+        _, past = attn.decode(q, k, v, past)
+        hist_k.append(k); hist_v.append(v)
+    assert past[4] == 1024 and len(past[0].extents) == 1
+    assert sig == (past[0].signature(), past[2].signature(), past[1].buf.data_ptr(), past[3].buf.data_ptr()), "a trigger moved something a graph holds"
+    counter.zero_()
+    g.replay()                                                 # appends (gk, gv) to the windows and attends over 1024 + R + 1 tokens
+    torch.cuda.synchronize()
+    K_all = torch.cat(hist_k + [gk], 2)
+    V_all = torch.cat(hist_v + [gv], 2)
+    want = _dense(gq, K_all, V_all, 1024, 0.7, hq // hkv)
+    torch.testing.assert_close(g_out.float(), want, rtol=4e-3, atol=2e-3)
+
+
+def test_full_table_consolidates_and_other_launch_forms_append_in_place(monkeypatch):
+    from mustafar_amd.cache import CompressedArena
+    torch.manual_seed(7)
+    bsz, hq, hkv, D = 1, 8, 2, 128
+    L0, steps = 256 + R + 255, 1 + 3 * 256 + 5
+    K0, V0 = (torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(2))
+    qs = [torch.randn(bsz, hq, 1, D, device=DEV).half() for _ in range(steps)]
+    ks = [torch.randn(bsz, hkv, 1, D, device=DEV).half() for _ in range(steps)]
+    vs = [torch.randn(bsz, hkv, 1, D, device=DEV).half() for _ in range(steps)]
+    monkeypatch.setattr(CompressedArena, "MAX_EXTENTS", 2)
+    o_ext, p_ext = _run(_attn(hq, hkv, extents=True), K0, V0, qs, ks, vs)       # 4 triggers: 2 extents, a consolidation, 1 more...
+    assert p_ext[4] == 256 + 4 * 256 and p_ext[0].total_tokens == p_ext[4] and len(p_ext[0].extents) <= 2 and p_ext[0].tokens >= 768
+    o_two, p_two = _run(_attn(hq, hkv, extents=True, structure="two_launch"), K0, V0, qs, ks, vs)
+    assert not p_two[0].extents and p_two[0].tokens == p_two[4] == p_ext[4]      # two launches cannot read extents: in-place append
+    want = _dense(qs[-1], torch.cat([K0] + ks, 2), torch.cat([V0] + vs, 2), p_ext[4], 0.7, hq // hkv)
+    torch.testing.assert_close(o_ext[-1].float(), want, rtol=4e-3, atol=2e-3)
+    torch.testing.assert_close(o_two[-1].float(), want, rtol=4e-3, atol=2e-3)
+    a, b = p_ext[0].to_reference(), p_two[0].to_reference()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(torch.cat(list(a[2])), torch.cat(list(b[2])))
