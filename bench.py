@@ -215,6 +215,10 @@ class Workload:
 
     def fused_state(self):
         self.cfg.api, self.cfg.arena = "fused", True
+        for p in self.pasts:   # every leg starts from the prefilled cache: extents a previous leg's trigger appended are dropped
+            for a in (p[0], p[2]):
+                if hasattr(a, "drop_extents"):
+                    a.drop_extents()
         return [self.attn.to_fused(p) for p in self.pasts]
 
     def bracket(self, run_steps):

@@ -65,6 +65,18 @@ def _cap_nz(halfs: int, slack: float) -> int:
     return _round_up(int(halfs * (1.0 + slack)) + 256, 8)
 
 
+_HEAD_INDEX = {}
+
+
+def _head_index(heads: int, device) -> torch.Tensor:
+    """arange(heads) as int32 on the device, kept (an arena per trigger and side is initialised from it)."""
+    key = (heads, str(device))
+    t = _HEAD_INDEX.get(key)
+    if t is None:
+        t = _HEAD_INDEX[key] = torch.arange(heads, dtype=torch.int32, device=device)
+    return t
+
+
 class CompressedArena:
     TILES_PER_TOKEN = 2   # head_dim 128 / 64
     MAX_EXTENTS = 64      # appended 256-token extents listed in the device table (16 k tokens of generation) before a consolidation
@@ -111,7 +123,7 @@ class CompressedArena:
 
     def _init_empty(self):
         """An arena that starts empty: stream starts of the heads, offset 0 of every head, flag 0."""
-        self.nz_offset.copy_((torch.arange(self.heads, dtype=torch.int64, device=self.device) * (self.nz_cap // 8)).to(torch.int32))
+        torch.mul(_head_index(self.heads, self.device), self.nz_cap // 8, out=self.nz_offset)
         self.idx[:, 0] = 0
         self._overflow.zero_()
         self._fresh = False
@@ -196,11 +208,20 @@ class CompressedArena:
         of each side (prune + compress in one launch: from_raw_pair), listed in the device tables."""
         if len(k_arena.extents) >= k_arena.MAX_EXTENTS or len(k_arena.extents) != len(v_arena.extents) or k_arena.tokens % 256:
             raise RuntimeError("append_extent_pair: extent table full (consolidate() first) or K / V out of step")
-        ek, ev = CompressedArena.from_raw_pair(k_rows, v_rows, 256, kth_k, kth_v, None, k_arena.slack)
+        # regions sized from what the base measured per token (+ 4 %): right the first time, no estimate to shrink afterwards (a head
+        # that needs more -- rows full of ties -- is answered by append_window_pair's repeat at the measured size)
+        ek = CompressedArena(k_arena.heads, "key", k_arena.device, 256, _cap_nz(k_arena._expected_append(256, kth_k), 0.0), k_arena.slack)
+        ev = CompressedArena(v_arena.heads, "value", v_arena.device, 256, _cap_nz(v_arena._expected_append(256, kth_v), 0.0), v_arena.slack)
+        ek._landing, ek._blk_scratch = k_arena._host_landing(), k_arena._scratch_for(256)   # (the base's pinned landing area and scratch serve its extents)
+        CompressedArena.append_window_pair(ek, ev, k_rows, v_rows, 256, kth_k, kth_v, expect=False)
         if ek._view.nz_head_stride == 0 or ev._view.nz_head_stride == 0:
             raise RuntimeError("append_extent_pair: extents need views with a stream stride")
         k_arena._list_extent(ek)
         v_arena._list_extent(ev)
+
+    def drop_extents(self) -> None:
+        """Back to the base tokens (the extents never touched them); their table entries are overwritten by the next ones."""
+        self.extents = []
 
     def consolidate(self) -> "CompressedArena":
         """One base arena holding everything (a copy of the cache; the addresses of the result are new)."""

@@ -234,6 +234,8 @@ class MustafarAttention:
         if self.cfg.arena and C and not isinstance(k_c, CompressedArena):
             k_c = CompressedArena.from_reference(k_c, "key", C, None, self.cfg.arena_slack)
             v_c = CompressedArena.from_reference(v_c, "value", C, None, self.cfg.arena_slack)
+        if self.cfg.extents and isinstance(k_c, CompressedArena):
+            k_c.ext_table, v_c.ext_table   # (exist before any graph that names them is captured: see decode_fused)
         if isinstance(k_w, Window):
             return (k_c, k_w, v_c, v_w, C, L)
         cap = self.cfg.residual_length + 256   # the longest window: the step that fires the trigger (model :324) holds R + 256 rows
@@ -315,8 +317,12 @@ class MustafarAttention:
         if use_arena:            # a failed asynchronous append is reported before the cache is read again (no host stall)
             k_c.poll()
             v_c.poll()
-            if cfg.extents and k_c._ext_table is None and not torch.cuda.is_current_stream_capturing():
-                k_c.ext_table, v_c.ext_table   # (the extent tables exist before a graph that names them is captured)
+            if cfg.extents and (k_c._ext_table is None or v_c._ext_table is None):
+                # the extent tables must exist BEFORE a graph that names them is captured: created inside a capture they would
+                # live in the graph's pool and their zero-fill would be replayed over the entries with every step
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("decode_fused: extent tables missing under graph capture (to_fused() creates them)")
+                k_c.ext_table, v_c.ext_table
         tail = (q.data_ptr(), k_w.buf.data_ptr(), v_w.buf.data_ptr(), kn.data_ptr(), vn.data_ptr(), w_len, k_w.cap,
                 scores.data_ptr(), ld, out.data_ptr(), ws.data_ptr(), split, C, BH, groups, math.sqrt(D),
                 step_counter.data_ptr() if step_counter is not None else None, mask_ptr, mask_stride, self.num_heads,
@@ -347,9 +353,12 @@ class MustafarAttention:
                 # prune (:325-326) + compress + append (:328-390) of the raw window rows in one launch, no host read
                 if C == 0:
                     k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, None, cfg.arena_slack)
+                    if cfg.extents:
+                        k_c.ext_table, v_c.ext_table
                 elif cfg.extents and k_c.tokens % 256 == 0 and L.mustafar_decode_reads_extents(groups, ld, flags):
                     if len(k_c.extents) >= k_c.MAX_EXTENTS:          # table full: one copy of the cache, then extents again
                         k_c, v_c = k_c.consolidate(), v_c.consolidate()
+                        k_c.ext_table, v_c.ext_table
                     CompressedArena.append_extent_pair(k_c, v_c, k_w.buf, v_w.buf, kth_k, kth_v)
                 else:
                     if k_c.extents:
