@@ -45,7 +45,8 @@ class MustafarConfig:
     arena: bool = False           # api="fused": keep the compressed cache in CompressedArena objects (in-place append)
     extents: bool = True          # arena: a 256-token trigger adds an extent instead of re-housing the cache (cache.py), where the
                                   # decode launch can read extents (GQA groups % 4 == 0, one-pass pair form)
-    arena_slack: float = 0.03       # an arena is housed at (1 + arena_slack) x the rows / stream bytes it holds (cache.py: DEFAULT_SLACK)
+    arena_slack: float = 0.03       # an arena that appends IN PLACE is housed at (1 + arena_slack) x the rows / stream bytes it holds
+                                    # (cache.py: DEFAULT_SLACK); one that grows by extents is housed exactly
     # api="fused": this instance's FMA engine ("dot2" | "valu" | "mfma"; None = the process default) and launch structure
     # ("one_pass" | "two_launch"; None = by size).  Carried in every call's `flags` (include/mustafar_hip.h): two instances in
     # one process run what each of them asks for.
@@ -181,6 +182,15 @@ class MustafarAttention:
     def dh_prune_value(self, value_states: torch.Tensor, target_sparsity=None) -> torch.Tensor:
         return compression.prune_magnitude(value_states, self.cfg.v_sparsity if target_sparsity is None else target_sparsity)
 
+    def _slack(self) -> float:
+        """Margin an arena is housed with: none where the cache grows by extents (nothing is ever appended in place), the
+        configured one where a trigger appends in place (other GQA shapes, two launches asked for)."""
+        cfg = self.cfg
+        if cfg.extents and _lib.load().mustafar_decode_reads_extents(self.num_key_value_groups, 32,
+                                                                     _lib.ENGINE_FLAGS[cfg.engine] | _lib.STRUCTURE_FLAGS[cfg.structure]):
+            return 0.0
+        return cfg.arena_slack
+
     def _ws(self, device):
         if self.Reduction_Workspace is None or self.Reduction_Workspace.device != device:
             self.Reduction_Workspace = torch.zeros(1, dtype=torch.float16, device=device)
@@ -201,7 +211,7 @@ class MustafarAttention:
             vs = value_states if value_states.is_contiguous() else value_states.contiguous()
             k_compressed, v_compressed = CompressedArena.from_raw_pair(
                 ks, vs, compressed_length, compression.kth_from_sparsity(self.cfg.k_sparsity, D),
-                compression.kth_from_sparsity(self.cfg.v_sparsity, D), None, self.cfg.arena_slack)
+                compression.kth_from_sparsity(self.cfg.v_sparsity, D), None, self._slack())
             del ks, vs
             k_local_window = key_states[:, :, compressed_length:, :].clone().contiguous()             # :427
             v_local_window = value_states[:, :, compressed_length:, :].clone().contiguous()           # :435
@@ -209,8 +219,8 @@ class MustafarAttention:
             k_pruned = self.dh_prune_key(key_states[:, :, :compressed_length, :])                     # :419
             v_pruned = self.dh_prune_value(value_states[:, :, :compressed_length, :])                 # :420
             if self.cfg.arena and self.cfg.api == "fused":   # (unreachable since the branch above takes every arena prefill; kept for callers that set arena late)
-                k_compressed = CompressedArena.from_pruned(k_pruned.reshape(total_batch_kv, -1, D), "key", None, self.cfg.arena_slack)
-                v_compressed = CompressedArena.from_pruned(v_pruned.reshape(total_batch_kv, -1, D), "value", None, self.cfg.arena_slack)
+                k_compressed = CompressedArena.from_pruned(k_pruned.reshape(total_batch_kv, -1, D), "key", None, self._slack())
+                v_compressed = CompressedArena.from_pruned(v_pruned.reshape(total_batch_kv, -1, D), "value", None, self._slack())
             else:
                 k_compressed = _compress(k_pruned.reshape(total_batch_kv, -1, D), "key")              # :422-426
                 v_compressed = _compress(v_pruned.reshape(total_batch_kv, -1, D), "value")            # :430-434
@@ -232,8 +242,8 @@ class MustafarAttention:
         """Wrap the two local windows of a reference-layout `past` into appendable buffers."""
         k_c, k_w, v_c, v_w, C, L = past
         if self.cfg.arena and C and not isinstance(k_c, CompressedArena):
-            k_c = CompressedArena.from_reference(k_c, "key", C, None, self.cfg.arena_slack)
-            v_c = CompressedArena.from_reference(v_c, "value", C, None, self.cfg.arena_slack)
+            k_c = CompressedArena.from_reference(k_c, "key", C, None, self._slack())
+            v_c = CompressedArena.from_reference(v_c, "value", C, None, self._slack())
         if self.cfg.extents and isinstance(k_c, CompressedArena):
             k_c.ext_table, v_c.ext_table   # (exist before any graph that names them is captured: see decode_fused)
         if isinstance(k_w, Window):
@@ -352,7 +362,7 @@ class MustafarAttention:
             if use_arena or (cfg.arena and C == 0):
                 # prune (:325-326) + compress + append (:328-390) of the raw window rows in one launch, no host read
                 if C == 0:
-                    k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, None, cfg.arena_slack)
+                    k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, None, self._slack())
                     if cfg.extents:
                         k_c.ext_table, v_c.ext_table
                 elif cfg.extents and k_c.tokens % 256 == 0 and L.mustafar_decode_reads_extents(groups, ld, flags):
