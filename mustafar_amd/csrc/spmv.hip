@@ -191,6 +191,17 @@ struct MetaB {         // tile metadata of one step (8 tiles) -- all SGPRs
     u32x8 ix;          // 8 stream offsets (half2 units)
 };
 
+// MUSTAFAR_META_EARLY (default): the NEXT step's bitmaps and offsets are requested in front of this step's gathers, so that the one
+// wait of the step (every lgkmcnt wait is a full drain) covers LDS and scalar-memory latency at once; 0: requested behind the
+// gather wait and waited for behind the FMAs (rounds 1-2: two waits per step, the second one all scalar-memory latency).
+// 1 = the matrix-pipe pair form (its coefficients sit in LDS: c3 38.1 -> 37.6 us); 2 = experiments: the G <= 2 forms too (c2: key 10.7 ->
+// 11.1 us, value 16.1 -> 16.5, one-pass 15.8 -> 16.3: their launches are latency chains of a few waves, the extra scalar spills cost
+// more than the wait saved) and the GQA-4 vector engines (140+ scalar registers short: the compiler then spills registers that loads
+// are still writing -- tools/check_smem_hazards.py).
+#ifndef MUSTAFAR_META_EARLY
+#define MUSTAFAR_META_EARLY 1
+#endif
+
 // Issue the scalar loads of the bitmaps / offsets of step S of a chunk (byte offsets are immediates).  Nothing may
 // read `m` before a metab_wait() that follows.
 #ifdef MUSTAFAR_PROBE_HOTMETA   // timing-only build: every wave reads the SAME 256 + 128 bytes of metadata (scalar-cache hits);
@@ -361,6 +372,7 @@ template <int G>
 __device__ __forceinline__ void chunk32(uint32_t adj, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx,
                                         const h16x2* const (&cp)[G], float (&acc)[G])
 {
+    constexpr bool kEarly = MUSTAFAR_META_EARLY > 1 && G <= 2;   // (experiment: see MUSTAFAR_META_EARLY)
     MetaB cur, nxt;
     u32x4 c[G];
     Gathered g;
@@ -368,11 +380,12 @@ __device__ __forceinline__ void chunk32(uint32_t adj, const uint64_t* __restrict
     coef_issue<G, 0>(c, cp);
     metab_wait(cur);
 #define MUSTAFAR_STEP(S)                  \
+    if constexpr (kEarly) metab_issue<S + 1>(nxt, bmp, idx); \
     gather8(cur, adj, g);                 \
     gather_wait<G>(g, c);                 \
-    metab_issue<S + 1>(nxt, bmp, idx);    \
+    if constexpr (!kEarly) metab_issue<S + 1>(nxt, bmp, idx); \
     fma8<G>(c, g, acc);                   \
-    metab_wait(nxt);                      \
+    if constexpr (kEarly) metab_ready(nxt); else metab_wait(nxt); \
     coef_issue<G, S + 1>(c, cp);          \
     cur = nxt;
     MUSTAFAR_STEP(0) MUSTAFAR_STEP(1) MUSTAFAR_STEP(2)
@@ -1975,14 +1988,6 @@ __device__ __forceinline__ void fma8_d2(const u32x4 (&c)[4], Gathered2& g, float
                  : [t1] "v"(g.t[1]), [t3] "v"(g.t[3]), [t5] "v"(g.t[5]), [t7] "v"(g.t[7]), MUSTAFAR_COPS(0), MUSTAFAR_COPS(1),
                    MUSTAFAR_COPS(2), MUSTAFAR_COPS(3));
 }
-
-// MUSTAFAR_META_EARLY (default): the NEXT step's bitmaps and offsets are requested in front of this step's gathers, so that the one
-// wait of the step (every lgkmcnt wait is a full drain) covers LDS and scalar-memory latency at once; 0: requested behind the
-// gather wait and waited for behind the FMAs (rounds 1-2: two waits per step, the second one all scalar-memory latency).
-// 1 = the matrix-pipe form only (its coefficients sit in LDS); 2 = the vector engines too (experiment: does not fit their registers).
-#ifndef MUSTAFAR_META_EARLY
-#define MUSTAFAR_META_EARLY 1
-#endif
 
 // The matrix-pipe engine on the lean addressing: the dot2 form's gather (tile pairs packed in one register, exact zeros where a lane
 // has no element), then per FOUR tiles one v_mfma_f32_4x4x4_16B_f16 in place of eight v_dot2 -- the lane's A fragment is the four

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round evidence in one GPU call: usage (GPU box, repo root): tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>/
 #   TCC traffic (c3), bench line (driver form), rocprofv3 kernel stats of the same command, SQ counters of the one-pass launch
-#   per engine (c3, c5), mem_spd harness, prefill-compression and append timings, the two reference entry points.
+#   per engine (c3, c5), mem_spd harness, prefill-compression and append timings, the two reference entry points, launch
+#   structures, the cost of a trigger that adds an extent.
 # Every profiler pass starts from an empty directory and keeps its output in a .err file; a failing step stops the script (set -e),
 # so nothing stale can be copied into profiles/ and a fault under the profiler does not go unnoticed.
 set -e
@@ -29,5 +30,6 @@ python3 tools/bench_compress.py c3 c4 2> $O/compress.err | grep cfg > $O/compres
 python3 tools/bench_append.py 2> $O/append.err | grep cfg > $O/append.txt
 MUSTAFAR_FMA_ENGINE=valu python3 tools/microbench.py --cfg c2 c3 c4 c5 --rows 1 --iters 30 2> $O/microbench.err | grep cfg > $O/microbench_valu.txt
 MUSTAFAR_FMA_ENGINE=mfma python3 tools/microbench.py --cfg c3 c4 c5 --rows 1 --iters 30 2>> $O/microbench.err | grep cfg > $O/microbench_mfma.txt
-python3 tools/quick.py --cfg c3 c4 c5 --set dot2 valu mfma valu:onepass=0 valu:lean=0 2> $O/quick.err | grep cfg > $O/structures.txt
+python3 tools/quick.py --cfg c3 c4 c5 --set dot2 valu mfma valu:onepass=0 valu:lean=0 mfma:lean=0 dot2:tbw=2 mfma:tbw=2 mfma:pslab=1 2> $O/quick.err | grep cfg > $O/structures.txt
+python3 tools/bench_extent_append.py 2> $O/extent_append.err | grep "x32" > $O/extent_append.txt
 echo "all done"; ls $O
