@@ -2623,7 +2623,10 @@ inline int onepass_target_wgs(bool pair)
 // kernel with whole blocks per wave, 0 the round-2 pair form; MUSTAFAR_LEAN_TBW=n: blocks per wave (1) / block pairs per
 // workgroup (2) instead of the automatic choice (raised when the slabs would not fit).
 int g_pair_slabs = 0;   // pair form, mustafar_tune(4, 1): a slab per pair instead of one per workgroup (kernel 1.1 us shorter at c3, row kernel 1.5 us longer)
-int g_lean = -1, g_lean_tbw = -1, g_lean_win_last = 0;   // (window workgroups behind the SpMV rows: the launch 0.8 us shorter at c3, the step 1.5 % slower)
+// g_lean_win_last: the pair form's window workgroups sit BEHIND the SpMV rows of the grid (mustafar_tune(3, 0): in front, round 3a).
+// In front they hold 434 of the chip's 2048 workgroup slots for their ~10 us while the SpMV rows wait; behind, they fill the tail
+// (matrix pipe c3 37.1 -> 36.2 us, c4 61.4 -> 60.0, c5 119.0 -> 115.3; dot2 +-0 at c3 / c4, 139.2 -> 137.3 at c5).
+int g_lean = -1, g_lean_tbw = -1, g_lean_win_last = 1;
 inline int onepass_lean()
 {
     if (g_lean < 0) {
@@ -2757,7 +2760,7 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
 
 extern "C" {
 
-int mustafar_abi_version(void) { return 102; }
+int mustafar_abi_version(void) { return 103; }
 
 int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
                    const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,
@@ -2913,9 +2916,12 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             const int nchunks = (window_capacity + kOneWinChunk - 1) / kOneWinChunk;
             int per_wg;   // 64-token blocks per workgroup
             if (lp) {
-                // one block pair per workgroup while that makes <= 4096 workgroups (c3: 3968), two beyond (c4 74.8 vs 78.9 us with
-                // four, c5 139.6 vs 145.5 with one); MUSTAFAR_ONEPASS_WGS / MUSTAFAR_LEAN_TBW override
-                per_wg = (int64_t)((ntb + 1) / 2) * gy <= 4096 ? 2 : 4;
+                // two block pairs per workgroup (each pair of waves runs its block loop twice) unless that leaves fewer than 1024
+                // workgroups: start-up and merge code are paid once per two blocks and the row kernel folds half the slabs.  With the
+                // window workgroups BEHIND the SpMV rows (below) this is the better shape at c3 too -- round 3a, window rows first:
+                // 3968 workgroups of one pair each (tokens/s, four vs two blocks per workgroup, windows last: matrix pipe c3 6204 vs
+                // 6050, c4 1877 vs 1719, c5 4070 vs 3900; dot2 c3 5122 vs 4992).  MUSTAFAR_ONEPASS_WGS / MUSTAFAR_LEAN_TBW override
+                per_wg = (int64_t)((ntb + 3) / 4) * gy >= 1024 ? 4 : 2;
                 (void)onepass_target_wgs(true);   // (reads MUSTAFAR_ONEPASS_WGS once)
                 if (g_onepass_wgs > 0) {
                     const int want = (g_onepass_wgs + gy - 1) / gy;

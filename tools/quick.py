@@ -43,7 +43,7 @@ def main():
             _lib.check(lib.mustafar_tune(0, int(kv.get("lean", 2))), "lean")
             _lib.check(lib.mustafar_tune(1, int(kv.get("tbw", 0))), "tbw")
             _lib.check(lib.mustafar_tune(2, int(kv.get("wgs", 0))), "wgs")
-            _lib.check(lib.mustafar_tune(3, int(kv.get("winlast", 0))), "winlast")
+            _lib.check(lib.mustafar_tune(3, int(kv.get("winlast", 1))), "winlast")
             _lib.check(lib.mustafar_tune(4, int(kv.get("pslab", 0))), "pslab")
             ex = w.self_check()
             dt, (ku, vu, n) = w.timed_graph(a.steps, 3)
