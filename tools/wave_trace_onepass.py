@@ -58,7 +58,7 @@ def main():
         _lib.check(lib.mustafar_tune(0, int(kv.get("lean", 2))), "lean")
         _lib.check(lib.mustafar_tune(1, int(kv.get("tbw", 0))), "tbw")
         _lib.check(lib.mustafar_tune(2, int(kv.get("wgs", 0))), "wgs")
-        _lib.check(lib.mustafar_tune(3, int(kv.get("winlast", 0))), "winlast")
+        _lib.check(lib.mustafar_tune(3, int(kv.get("winlast", 1))), "winlast")
         priv = [(p[0], p[1].clone(), p[2], p[3].clone(), p[4], p[5]) for p in state]
         for _ in range(3):
             w.attn.decode_fused(w.qs[0], w.ks[0], w.vs[0], priv[0])
@@ -106,6 +106,17 @@ def main():
                 else:
                     print(f"       value      {pct(th[:, 5] - th[:, 3])}")
                 print(f"       merge/exit {pct(th[:, 6] - th[:, 5])}")
+            # placement: waves per CU and when each CU / XCC is done (HW_ID bits 8..15 = CU, shader array, shader engine; XCC_ID bits 0..3)
+            hw = r[:, 8]
+            cu = ((hw >> np.uint64(32)) & np.uint64(0xf)).astype(np.int64) * 256 + ((hw >> np.uint64(8)) & np.uint64(0xff)).astype(np.int64)
+            cus, inv, cnt = np.unique(cu, return_inverse=True, return_counts=True)
+            cu_end = np.array([t[inv == i, 6].max() for i in range(len(cus))])
+            print(f"     CUs used: {len(cus)}; waves per CU {pct(cnt)}; last wave of a CU ends {pct(cu_end)}")
+            for nw in sorted(set(cnt.tolist())):
+                sel_cu = cnt == nw
+                print(f"       CUs with {nw:3d} waves: {sel_cu.sum():4d}, end of their last wave {pct(cu_end[sel_cu], (10, 50, 90))}")
+            xcc = (cus // 256)
+            print("     end of the last wave per XCC: " + " ".join(f"{cu_end[xcc == x].max():6.2f}" for x in sorted(set(xcc.tolist()))))
             edges = np.linspace(0, span, 11)
             occ = [(np.minimum(t[:, 6], edges[i + 1]) - np.maximum(t[:, 0], edges[i])).clip(min=0).sum() / (edges[i + 1] - edges[i]) / 1024 for i in range(10)]
             print("     waves/SIMD per tenth of the span: " + " ".join(f"{o:5.2f}" for o in occ))
