@@ -546,6 +546,13 @@ __device__ __forceinline__ uint32_t bnd_load(const uint32_t* __restrict__ idx_t,
     return idx_t[(lane < 5 ? lane : 0) * kChunkTiles];
 }
 __device__ __forceinline__ uint32_t bnd_get(uint32_t bnd, int k) { return __builtin_amdgcn_readlane(bnd, k); }
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p)   // a pointer every lane holds alike, moved to scalar registers
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
 
 // Pull the metadata lines of one 64-token block (16 x 64 B of bitmaps, 9 of offsets) and, for the value kernel,
 // its coefficient lines (2 x 64 B of probabilities per head) into L2 with ONE vector load, 4 bytes per line.
@@ -2378,12 +2385,14 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         const int e = (tb0 - a.nb0) >> 2;
         const mustafar_cache_view ek = a.k_ext[e], ev = a.v_ext[e];
         const int64_t t0 = (int64_t)(a.nb0 + 4 * e) * kTilesPerTb;
-        kb = ek.bmp + (int64_t)kvh * ek.bmp_head_stride - t0;
-        ki = ek.idx + (int64_t)kvh * ek.idx_head_stride - t0;
-        kn = static_cast<const unsigned char*>(ek.nz) + 16ull * (uint64_t)kvh * (uint64_t)ek.nz_head_stride;
-        vb = ev.bmp + (int64_t)kvh * ev.bmp_head_stride - t0;
-        vi = ev.idx + (int64_t)kvh * ev.idx_head_stride - t0;
-        vn = static_cast<const unsigned char*>(ev.nz) + 16ull * (uint64_t)kvh * (uint64_t)ev.nz_head_stride;
+        // (uniform_ptr: the entries are the same in every lane, and the block loop hands these pointers to scalar loads -- whatever
+        // kind of load the compiler chose for the table)
+        kb = uniform_ptr(ek.bmp + (int64_t)kvh * ek.bmp_head_stride - t0);
+        ki = uniform_ptr(ek.idx + (int64_t)kvh * ek.idx_head_stride - t0);
+        kn = uniform_ptr(static_cast<const unsigned char*>(ek.nz) + 16ull * (uint64_t)kvh * (uint64_t)ek.nz_head_stride);
+        vb = uniform_ptr(ev.bmp + (int64_t)kvh * ev.bmp_head_stride - t0);
+        vi = uniform_ptr(ev.idx + (int64_t)kvh * ev.idx_head_stride - t0);
+        vn = uniform_ptr(static_cast<const unsigned char*>(ev.nz) + 16ull * (uint64_t)kvh * (uint64_t)ev.nz_head_stride);
     } else {
         kb = k_bmp + (int64_t)kvh * (k_bmp_stride ? k_bmp_stride : tiles);
         ki = k_idx + (int64_t)kvh * (k_idx_stride ? k_idx_stride : tiles + 1);
