@@ -343,9 +343,17 @@ class MustafarAttention:
             if use_arena and C > k_c.tokens:
                 # the cache has grown by extents (or, under a capture ahead of a trigger, is about to): base views + device tables
                 if not L.mustafar_decode_reads_extents(groups, ld, flags):
-                    raise RuntimeError("decode_fused: this launch form cannot read a cache that grew by extents; consolidate() it")
-                err = L.mustafar_decode_attention_extents(st, k_c.view_ptr(), v_c.view_ptr(), k_c.tokens, k_c.ext_table.data_ptr(),
-                                                          v_c.ext_table.data_ptr(), *tail)
+                    # an engine / structure switch after the cache grew: this form reads ONE view -- one copy of the cache.  (Not
+                    # possible under a capture, nor for a graph captured ahead of a trigger, whose extent does not exist yet.)
+                    if torch.cuda.is_current_stream_capturing() or k_c.tokens + 256 * len(k_c.extents) < C:
+                        raise RuntimeError("decode_fused: this launch form cannot read a cache that grows by extents "
+                                           "(MustafarConfig(extents=False), or consolidate() the arenas first)")
+                    k_c, v_c = k_c.consolidate(), v_c.consolidate()
+                    k_c.ext_table, v_c.ext_table
+                    err = L.mustafar_decode_attention_view(st, k_c.view_ptr(), v_c.view_ptr(), *tail)
+                else:
+                    err = L.mustafar_decode_attention_extents(st, k_c.view_ptr(), v_c.view_ptr(), k_c.tokens, k_c.ext_table.data_ptr(),
+                                                              v_c.ext_table.data_ptr(), *tail)
             elif use_arena:
                 err = L.mustafar_decode_attention_view(st, k_c.view_ptr(), v_c.view_ptr(), *tail)
             else:

@@ -138,3 +138,25 @@ def test_full_table_consolidates_and_other_launch_forms_append_in_place(monkeypa
     torch.testing.assert_close(o_two[-1].float(), want, rtol=4e-3, atol=2e-3)
     a, b = p_ext[0].to_reference(), p_two[0].to_reference()
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(torch.cat(list(a[2])), torch.cat(list(b[2])))
+
+
+def test_engine_switch_to_a_form_without_extents_consolidates():
+    """A cache that grew by extents handed to a launch form that reads one view (two launches asked for): decode_fused re-houses it
+    once and goes on; outputs equal dense attention before and after."""
+    torch.manual_seed(8)
+    bsz, hq, hkv, D = 1, 8, 2, 128
+    L0 = 256 + R + 250
+    K0, V0 = (torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(2))
+    a_ext, a_two = _attn(hq, hkv), _attn(hq, hkv, structure="two_launch")
+    past = a_ext.to_fused(a_ext.build_cache(K0.clone(), V0.clone()))
+    hk, hv = [K0], [V0]
+    for i in range(12):                                        # the trigger fires at step 6; from step 9 on the other form decodes
+        q, k, v = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+        hk.append(k); hv.append(v)
+        out, past = (a_ext if i < 9 else a_two).decode(q, k, v, past)
+        if i in (8, 9, 11):
+            want = _dense(q, torch.cat(hk, 2), torch.cat(hv, 2), past[4], 0.7, hq // hkv)
+            torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3, msg=lambda m, i=i: f"step {i}: {m}")
+        if i == 8:
+            assert len(past[0].extents) == 1 and past[0].tokens == 256
+    assert not past[0].extents and past[0].tokens == past[4] == 512
