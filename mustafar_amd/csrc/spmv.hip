@@ -2330,8 +2330,9 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_lean_kernel(
 // to cover for them (probe builds: -12 us without the stream loads, -8 us with hot metadata; the pair grain: -2 / -2): half-size
 // waves, twice as many, is the grain at which the launch is bound by instruction issue, so this is the form that runs by default.
 //   grid: x = ceil(T / 64 / a.tb_per_wg) (a.tb_per_wg = blocks per WORKGROUP, even), y as decode_onepass_lean_kernel.
-//   e round trip: the EVEN wave stores the block's four e segments and waits vmcnt(0) before the barrier; both waves then
-//   scalar-load them (the invariant stated at decode_onepass_lean_kernel, with "the same wave" read as "the same pair").
+//   e round trip (vector engines): each wave stores the e segments of the two heads it finishes (the softmax step is split between
+//   the waves of a pair) and waits vmcnt(0) before the barrier; both waves then scalar-load all four segments (the invariant stated
+//   at decode_onepass_lean_kernel, with "the same wave" read as "the same pair").  Matrix-pipe engine: e goes into the pair's LDS table.
 // Compiled for 8 waves per SIMD (<= 64 vector registers; the scalar file then spills ~45 values to lanes of a vector register):
 // with the stream loads non-temporal the launch is bound by how many waves are there to cover for each other (c3, dot2 form:
 // 7 waves 45.6 us, 8 waves 44.3 us).  MUSTAFAR_LP_WAVES: experiment knob (tools/build_variant.sh).
@@ -2350,7 +2351,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     constexpr int G = 4;
     // matrix-pipe engine: behind the stage windows, the q rows of the four heads ([4][kKeyTabStride]) and one e table per pair ([4][kValTabStride])
     constexpr int kTabBytes = ENG == 1 ? 4 * kKeyTabStride + 2 * 4 * kValTabStride : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes + 2 * G * 4];   // (+ the pairs' rescale factors)
     MUSTAFAR_PTRACE_BEGIN();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2406,8 +2407,14 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     const h16* mrow = a.mask.ptr ? a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride : nullptr;
     unsigned char* lds = smem + wave * kStageBytes;
     const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
-    // exchange area of the pair: the ODD wave's stage window (dead between the phases): 4 x 64 partial scores, then 4 factors
-    float* xch = reinterpret_cast<float*>(smem + (2 * pair + 1) * kStageBytes);
+    // The softmax step is SPLIT between the two waves of a pair: the even wave finishes heads 0 and 1, the odd wave heads 2 and 3
+    // (round 3a: the even wave did all four while the odd wave waited at the barrier).  Each wave leaves the partial scores of the
+    // partner's two heads in its OWN stage window (dead from the end of its key phase to the start of its value phase) and reads
+    // the partner's after the barrier; the four rescale factors of the pair travel through `alf` (behind windows and tables).
+    float* xch_out = reinterpret_cast<float*>(lds);                                           // [2][64] partial scores for the partner
+    const float* xch_in = reinterpret_cast<const float*>(smem + (wave ^ 1) * kStageBytes);    // the partner's, for my two heads
+    float* alf = reinterpret_cast<float*>(smem + kWaves * kStageBytes + kTabBytes) + pair * G;
+    const int h0 = odd ? 2 : 0;   // my heads: h0, h0 + 1; the partner's: 2 - h0, 3 - h0
     constexpr float kEScaleLog2 = ENG == 2 ? 15.f : 0.f;
 
     uint32_t ctab_q = 0, ctab_e = 0;
@@ -2422,9 +2429,11 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         ctab_q = (uint32_t)reinterpret_cast<uintptr_t>(tab) + (lane & 3) * kKeyTabStride;
         ctab_e = (uint32_t)reinterpret_cast<uintptr_t>(ptab) + (lane & 3) * kValTabStride;
     }
-    float m_run[G], l_run[G], acc[G];   // acc: the wave's output half (even: channels 0..63, odd: 64..127); m_run, l_run live in the even wave
+    float m_run[2], l_run[2], acc[G];   // acc: the wave's output half (even: channels 0..63, odd: 64..127), four heads; m_run, l_run: my two heads
 #pragma unroll
-    for (int h = 0; h < G; h++) { m_run[h] = -INFINITY; l_run[h] = 0.f; acc[h] = 0.f; }
+    for (int h = 0; h < G; h++) acc[h] = 0.f;
+    m_run[0] = m_run[1] = -INFINITY;
+    l_run[0] = l_run[1] = 0.f;
 #pragma unroll 1
     for (int t = tb0; t < tb_end; t += kWaves / 2) {   // workgroup-uniform: every wave reaches the barriers below
         const int tb = t + pair;
@@ -2435,7 +2444,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         const uint64_t* vbt = vb + (int64_t)tbc * kTilesPerTb;
         const uint32_t* vit = vi + (int64_t)tbc * kTilesPerTb;
         h16* eblk = eb + (int64_t)tbc * (G * 64);
-        float s[G], alpha[G];
+        float s[G], alpha[G], own[2] = {0.f, 0.f};   // own: the partial scores of my two heads
 #pragma unroll
         for (int h = 0; h < G; h++) { s[h] = 0.f; alpha[h] = 1.f; }
         uint32_t bnd_v = 0, pfv = 0;
@@ -2452,44 +2461,37 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
             // scalar loads came for them (c3: 44.4 -> 43.7 us; without any prefetch the launch takes 62 us)
             bnd_v = bnd_load(vit, lane);
             pfv = odd ? prefetch_meta_all<64, 64>(vbt, vit, lane) : prefetch_meta_all<0, 64>(vbt, vit, lane);
-            if (odd) {
-#pragma unroll
-                for (int h = 0; h < G; h++) xch[h * 64 + lane] = s[h];
-            }
+            // (static indices under a wave-uniform branch: `s[odd ? 0 : 2]` would move the array to scratch memory)
+            if (odd) { xch_out[lane] = s[0]; xch_out[64 + lane] = s[1]; own[0] = s[2]; own[1] = s[3]; }
+            else     { xch_out[lane] = s[2]; xch_out[64 + lane] = s[3]; own[0] = s[0]; own[1] = s[1]; }
         }
         MUSTAFAR_PTRACE_STAMP(2);
         __syncthreads();
-        if (active && !odd) {
+        if (active) {
+            float al[2];
 #pragma unroll
-            for (int h = 0; h < G; h++) {
-                float x = scaled((h16)(s[h] + xch[h * 64 + lane]), a.inv_sqrt_d);   // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
+            for (int j = 0; j < 2; j++) {
+                float x = scaled((h16)(own[j] + xch_in[j * 64 + lane]), a.inv_sqrt_d);   // (even + odd in either wave: the same sum)   // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
                 if (mrow) x = masked(x, mk);
-                const float m_new = uniform_f(fmaxf(m_run[h], wave_max(x)));
-                alpha[h] = uniform_f(__expf(m_run[h] - m_new));   // 0 for the first block (m_run = -inf)
+                const float m_new = uniform_f(fmaxf(m_run[j], wave_max(x)));
+                al[j] = uniform_f(__expf(m_run[j] - m_new));   // 0 for the first block (m_run = -inf)
                 const h16 e = (h16)__builtin_amdgcn_exp2f((x - m_new) * 1.44269504f + kEScaleLog2);
-                if constexpr (ENG == 1) *reinterpret_cast<h16*>(ptab + h * kValTabStride + lane * 2) = e;
-                else                    eblk[h * 64 + lane] = e;
-                l_run[h] = uniform_f(l_run[h] * alpha[h] + wave_sum((float)e));
-                m_run[h] = m_new;
+                if constexpr (ENG == 1) *reinterpret_cast<h16*>(ptab + (h0 + j) * kValTabStride + lane * 2) = e;
+                else                    eblk[(h0 + j) * 64 + lane] = e;
+                l_run[j] = uniform_f(l_run[j] * al[j] + wave_sum((float)e));
+                m_run[j] = m_new;
             }
-            if (lane < G) {
-                float mine = alpha[0];
-#pragma unroll
-                for (int h = 1; h < G; h++) mine = (lane == h) ? alpha[h] : mine;
-                xch[G * 64 + lane] = mine;
-            }
-            if constexpr (ENG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the e stores have reached L2 before the pair's scalar loads
+            if (lane < 2) alf[h0 + lane] = lane ? al[1] : al[0];
+            if constexpr (ENG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my e stores have reached L2 before the pair's scalar loads
         }
         __syncthreads();
         MUSTAFAR_PTRACE_STAMP(3);
         if (active) {
-            if (odd) {
 #pragma unroll
-                for (int h = 0; h < G; h++) alpha[h] = xch[G * 64 + h];
-            }
+            for (int h = 0; h < G; h++) alpha[h] = alf[h];
 #pragma unroll
             for (int h = 0; h < G; h++) acc[h] *= alpha[h];
-            // (the odd wave's LDS reads above are issued before its value phase rewrites the window: one wave, in order)
+            // (the partner read my outgoing partial scores before the barrier above; my value phase now rewrites the window)
             if (odd) lean_block_phase<ENG, 64 * 2, true, 2, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
             else     lean_block_phase<ENG, 64 * 2, true, 0, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
             prefetch_done(pfv);
@@ -2497,22 +2499,16 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         MUSTAFAR_PTRACE_STAMP(5);
     }
     if (a.pair_slabs) {
-        // ---- a slab per pair: each wave stores its output half as it holds it, the even wave adds (maximum, sum) -- no exchange, no
+        // ---- a slab per pair: each wave stores its output half as it holds it and the (maximum, sum) of its two heads -- no exchange, no
         // barrier; the row kernel folds twice as many slabs (c3: 126).  A pair without a block leaves a slab of weight zero.
         constexpr float kOut = ENG == 2 ? 0x1p-15f : 1.f;   // the e scale leaves here (a power of two: exact)
         const int64_t slab = (int64_t)blockIdx.x * 2 + pair;
         float* so = a.ws_o + (slab * a.BH + bh0) * kD + (odd ? 64 : 0) + lane;
 #pragma unroll
         for (int h = 0; h < G; h++) so[h * kD] = acc[h] * kOut;
-        if (!odd && lane < G) {
-            float mm = m_run[0], ll = l_run[0];
-#pragma unroll
-            for (int h = 1; h < G; h++) {
-                mm = (lane == h) ? m_run[h] : mm;
-                ll = (lane == h) ? l_run[h] : ll;
-            }
-            *reinterpret_cast<float2*>(a.ws_ml + (slab * a.BH + bh0 + lane) * 2) = make_float2(mm, ll * kOut);
-        }
+        if (lane < 2)   // (maximum, sum) of my two heads
+            *reinterpret_cast<float2*>(a.ws_ml + (slab * a.BH + bh0 + h0 + lane) * 2) =
+                make_float2(lane ? m_run[1] : m_run[0], (lane ? l_run[1] : l_run[0]) * kOut);
         MUSTAFAR_PTRACE_END(7);
         return;
     }
@@ -2521,20 +2517,15 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     float* s_m = red + kWaves * G * 64;                          // [2 pairs][G]
     float* s_l = s_m + 2 * G;                                    // [2 pairs][G]
     __syncthreads();   // every wave is done with its stage window
-    if (lane < G && !odd) {
-        float mine = m_run[0];
-#pragma unroll
-        for (int h = 1; h < G; h++) mine = (lane == h) ? m_run[h] : mine;
-        s_m[pair * G + lane] = mine;
-    }
+    if (lane < 2) s_m[pair * G + h0 + lane] = lane ? m_run[1] : m_run[0];   // (each wave: the maxima of its two heads)
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < G; h++) {
-        const float mw = s_m[pair * G + h];                      // the PAIR's maximum (an odd wave carries no softmax state of its own)
+        const float mw = s_m[pair * G + h];                      // the PAIR's maximum of head h (kept by one of its two waves)
         const float M = fmaxf(s_m[h], s_m[G + h]);
         // a pair without blocks weighs nothing; the e scale leaves here (a power of two: exact)
         const float scale = (mw == -INFINITY) ? 0.f : __expf(mw - M) * (ENG == 2 ? 0x1p-15f : 1.f);
-        if (lane == 0 && !odd) s_l[pair * G + h] = l_run[h] * scale;
+        if (lane == 0 && (h >> 1) == (int)odd) s_l[pair * G + h] = l_run[h & 1] * scale;   // (the wave that finished head h)
         red[(wave * G + h) * 64 + lane] = acc[h] * scale;
     }
     __syncthreads();
