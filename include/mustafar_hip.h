@@ -156,6 +156,11 @@ typedef struct mustafar_cache_view {
  * before the first call that names it, and never changed: a captured hipGraph of a call stays valid while the cache grows
  * behind it.  T_base and T - T_base are multiples of 256.  Read by the pair form of the one-pass launch (GQA groups % 4 == 0,
  * ld_scores % 32 == 0; mustafar_decode_reads_extents() tells); MUSTAFAR_EINVAL otherwise -- consolidate into one view then.
+ *   T_device   NULL: T is the number of compressed tokens.  Otherwise a device int holding the compressed tokens IN USE
+ *              (T_base <= *T_device <= T, a multiple of 256 beyond T_base), and T is the CAPACITY the launch is sized for: grid,
+ *              slabs, score scratch (ld_scores >= T + window capacity), mask columns.  The caller adds 256 to *T_device when a
+ *              trigger has listed an extent (and takes 256 off its window_len_extra counter, the windows having slid): ONE
+ *              captured graph of the step then serves every cache length up to T (tests/test_gpu_extents.py).
  */
 int mustafar_decode_attention_extents(void* stream, const mustafar_cache_view* k_base, const mustafar_cache_view* v_base, int T_base,
                                       const mustafar_cache_view* k_extents, const mustafar_cache_view* v_extents,
@@ -163,7 +168,7 @@ int mustafar_decode_attention_extents(void* stream, const mustafar_cache_view* k
                                       int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
                                       int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
                                       const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
-                                      int heads_per_mask_row, uint32_t flags);
+                                      int heads_per_mask_row, uint32_t flags, const int32_t* T_device);
 int mustafar_decode_reads_extents(int num_key_value_groups, int ld_scores, uint32_t flags);
 
 /* mustafar_decode_attention over two cache views (same semantics, same remaining arguments). */

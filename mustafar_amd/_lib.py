@@ -35,7 +35,7 @@ SIGNATURES = {
                                               ctypes.c_float, _vp, _vp, _i64, _i32, ctypes.c_uint32]),
     "mustafar_decode_attention_extents": (_i32, [_vp, _view_p, _view_p, _i32, _vp, _vp] + [_vp] * 5 +
                                           [_i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_float, _vp, _vp, _i64, _i32,
-                                           ctypes.c_uint32]),
+                                           ctypes.c_uint32, _vp]),
     "mustafar_decode_reads_extents": (_i32, [_i32, _i32, ctypes.c_uint32]),
     "mustafar_cache_append_bitmap_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32, _vp]),
     "mustafar_cache_append_bitmap_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _view_p, _i32, _vp]),

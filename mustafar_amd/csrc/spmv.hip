@@ -1481,6 +1481,9 @@ struct OneArgs {   // operands of the one-pass launch beyond the two caches (by 
     const mustafar_cache_view* k_ext = nullptr;
     const mustafar_cache_view* v_ext = nullptr;
     int nb0 = 0;
+    // tokens in use as a DEVICE quantity (extents only): T above is then the capacity the launch was sized for -- grid, slabs, score
+    // scratch, mask columns -- and a captured graph of the launch stays valid while the cache grows up to it
+    const int* t_dev = nullptr;
 };
 
 // Window workgroup: 64 window tokens of one head batch -> scores, softmax partial, p.V partial -> slab (S + chunk).
@@ -1492,9 +1495,9 @@ struct WinOneArgs {
     int mask_heads, T, groups, BH, w_len, w_cap, nchunks;
     float inv_sqrt_d;
 };
-__device__ __forceinline__ WinOneArgs win_args(const OneArgs& a)
+__device__ __forceinline__ WinOneArgs win_args(const OneArgs& a, int T_used = -1)   // T_used: the tokens in use when a.T is a capacity
 {
-    return WinOneArgs{a.q, a.ws_o, a.ws_ml, a.k_win, a.v_win, a.k_new, a.v_new, a.mask.ptr, a.mask.stride, a.mask.heads, a.T, a.groups, a.BH,
+    return WinOneArgs{a.q, a.ws_o, a.ws_ml, a.k_win, a.v_win, a.k_new, a.v_new, a.mask.ptr, a.mask.stride, a.mask.heads, T_used >= 0 ? T_used : a.T, a.groups, a.BH,
                       window_len(a.w_extra, a.w_len, a.w_cap), a.w_cap, a.nchunks, a.inv_sqrt_d};
 }
 template <int G>
@@ -2359,7 +2362,11 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     const int wy = a.win_rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
     if (wy >= 0 && wy < wrows) {   // dense window
         const int task = wy * gridDim.x + blockIdx.x;
-        if (task < (int)(gridDim.y - wrows) * a.nchunks) onepass_window_wg<G>(smem, win_args(a), task, a.pair_slabs ? 2 * gridDim.x : gridDim.x);
+        if (task < (int)(gridDim.y - wrows) * a.nchunks) {
+            int T_used = -1;
+            if constexpr (EXT) { if (a.t_dev) T_used = __builtin_amdgcn_readfirstlane(*a.t_dev); }
+            onepass_window_wg<G>(smem, win_args(a, T_used), task, a.pair_slabs ? 2 * gridDim.x : gridDim.x);
+        }
         MUSTAFAR_PTRACE_END(5);
         return;
     }
@@ -2367,9 +2374,26 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     const int hb_per_kv = a.groups >> 2;
     const int kvh = hb_per_kv == 1 ? by : by / hb_per_kv;
     const int bh0 = kvh * a.groups + (by - kvh * hb_per_kv) * G;
-    const int ntb = a.T >> 6;
+    const int ntb_cap = a.T >> 6;   // what the launch was sized for
+    int ntb = ntb_cap;              // blocks in use
+    if constexpr (EXT) { if (a.t_dev) ntb = min(ntb_cap, __builtin_amdgcn_readfirstlane(*a.t_dev) >> 6); }
     const int tb0 = blockIdx.x * a.tb_per_wg;
     const int tb_end = min(ntb, tb0 + a.tb_per_wg);
+    if constexpr (EXT) {
+        if (tb0 >= ntb) {   // a workgroup beyond the tokens in use (the cache has not grown into its blocks yet): slabs of weight zero
+            const int nsl = a.pair_slabs ? 2 : 1;
+            for (int sl = 0; sl < nsl; sl++) {
+                const int64_t slab = (int64_t)blockIdx.x * nsl + sl;
+                // (every thread stores, some the same bytes: no divergent region around the block loop's EXEC-owning asm statements)
+                float* so = a.ws_o + (slab * a.BH + bh0) * kD;
+                so[threadIdx.x] = 0.f;
+                so[kThreads + threadIdx.x] = 0.f;
+                *reinterpret_cast<float2*>(a.ws_ml + (slab * a.BH + bh0 + (threadIdx.x & (G - 1))) * 2) = make_float2(-INFINITY, 0.f);
+            }
+            MUSTAFAR_PTRACE_END(7);
+            return;
+        }
+    }
     const int pair = wave >> 1;
     const bool odd = wave & 1;
     const int64_t tiles = (int64_t)(EXT ? a.nb0 : ntb) * kTilesPerTb;
@@ -2403,7 +2427,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         vn = v_nz + 16ull * (v_nz_stride ? (uint64_t)kvh * v_nz_stride : (uint64_t)v_nz_off[kvh]);
     }
     const h16* qb = a.q + (int64_t)bh0 * kD;
-    h16* eb = a.e_rows + (int64_t)by * ntb * (G * 64);
+    h16* eb = a.e_rows + (int64_t)by * ntb_cap * (G * 64);
     const h16* mrow = a.mask.ptr ? a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride : nullptr;
     unsigned char* lds = smem + wave * kStageBytes;
     const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
@@ -2861,7 +2885,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                      int ld_scores, void* out, void* workspace, int Split_K, int T, int Batch_Size, int num_key_value_groups,
                      float sqrt_d, const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
                      int heads_per_mask_row, uint32_t flags, const mustafar_cache_view* k_ext = nullptr,
-                     const mustafar_cache_view* v_ext = nullptr, int T_base = 0)
+                     const mustafar_cache_view* v_ext = nullptr, int T_base = 0, const int32_t* T_device = nullptr)
 {
     const int groups = num_key_value_groups;
     const bool extents = k_ext != nullptr;   // (validated by mustafar_decode_attention_extents)
@@ -2946,6 +2970,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                 a.k_ext = k_ext;
                 a.v_ext = v_ext;
                 a.nb0 = T_base / 64;
+                a.t_dev = T_device;
             }
             const dim3 grid(S1, gy + win_rows);
             hipEvent_t e0 = prof ? g_prof.ev[4 * g_prof.n] : nullptr, e1 = prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr;
@@ -3112,9 +3137,10 @@ int mustafar_decode_attention_extents(void* stream, const mustafar_cache_view* k
                                       int window_len, int window_capacity, void* scores, int ld_scores, void* out, void* workspace,
                                       int Split_K, int T, int Batch_Size, int num_key_value_groups, float sqrt_d,
                                       const int32_t* window_len_extra, const void* attention_mask, int64_t mask_row_stride,
-                                      int heads_per_mask_row, uint32_t flags)
+                                      int heads_per_mask_row, uint32_t flags, const int32_t* T_device)
 {
     if (!k_base || !v_base || T_base <= 0 || (T_base & 255) || T < T_base || ((T - T_base) & 255)) return MUSTAFAR_EINVAL;
+    if (T_device && T == T_base) return MUSTAFAR_EINVAL;   // (a capacity of exactly the base tokens: nothing to grow into)
     if (T == T_base)   // no appended extent: the plain call
         return decode_attention(stream, *k_base, *v_base, q, k_window, v_window, k_new, v_new, window_len, window_capacity, scores, ld_scores,
                                 out, workspace, Split_K, T, Batch_Size, num_key_value_groups, sqrt_d, window_len_extra, attention_mask,
@@ -3122,7 +3148,7 @@ int mustafar_decode_attention_extents(void* stream, const mustafar_cache_view* k
     if (!k_extents || !v_extents || k_base->nz_head_stride == 0 || v_base->nz_head_stride == 0) return MUSTAFAR_EINVAL;
     return decode_attention(stream, *k_base, *v_base, q, k_window, v_window, k_new, v_new, window_len, window_capacity, scores, ld_scores,
                             out, workspace, Split_K, T, Batch_Size, num_key_value_groups, sqrt_d, window_len_extra, attention_mask,
-                            mask_row_stride, heads_per_mask_row, flags, k_extents, v_extents, T_base);
+                            mask_row_stride, heads_per_mask_row, flags, k_extents, v_extents, T_base, T_device);
 }
 
 int mustafar_decode_reads_extents(int num_key_value_groups, int ld_scores, uint32_t flags)

@@ -278,7 +278,8 @@ class MustafarAttention:
         return sc, ws
 
     def decode_fused(self, query_states, key_states, value_states, past, step_counter: Optional[torch.Tensor] = None,
-                     attention_mask: Optional[torch.Tensor] = None):
+                     attention_mask: Optional[torch.Tensor] = None, t_device: Optional[torch.Tensor] = None,
+                     t_capacity: Optional[int] = None):
         """Same contract as decode() with api="native"; windows are `Window` objects appended in place.
 
         `attention_mask` is the hook's additive mask [bsz, 1, 1, kv_seq_len] (model :293-301), applied inside the softmax
@@ -289,12 +290,22 @@ class MustafarAttention:
         `step_counter` (int32 device tensor, optional) is added to the window length inside the kernels, so that a
         captured graph of this call can be replayed for consecutive steps (advance it with mustafar_counter_add once
         per step); the host-side lengths/`kv_seq_len` of the returned `past` then describe the FIRST replay and the
-        256-token trigger is the caller's business (see bench.py)."""
+        256-token trigger is the caller's business (see bench.py).
+
+        `t_device` (int32 device tensor) + `t_capacity`: the compressed tokens IN USE as a device quantity and the capacity the
+        launch is sized for (a cache that grows by extents only).  ONE captured graph of the call then serves every compressed
+        length up to `t_capacity`: after a trigger (run eagerly, outside the graph) the caller adds 256 to `t_device` and takes
+        256 off `step_counter` (tests/test_gpu_extents.py)."""
         cfg = self.cfg
         bsz, _, q_len, D = query_states.shape
         assert q_len == 1 and D == 128
         BH, Bkv, groups = bsz * self.num_heads, bsz * self.num_key_value_heads, self.num_key_value_groups
         k_c, k_w, v_c, v_w, C, _ = self.to_fused(past)
+        C_used = C
+        if t_device is not None:   # the launch is sized for the capacity; the kernels read the tokens in use from `t_device`
+            if t_capacity is None or t_capacity < C or (t_capacity - C) % 256 or not isinstance(k_c, CompressedArena) or t_capacity <= k_c.tokens:
+                raise ValueError("decode_fused: t_device needs an arena cache and t_capacity = compressed length + a multiple of 256, beyond the base tokens")
+            C = t_capacity
         kv_seq_len = past[-1] + 1
         w_len = k_w.len + 1
         k_w.reserve(w_len)
@@ -345,7 +356,7 @@ class MustafarAttention:
                 if not L.mustafar_decode_reads_extents(groups, ld, flags):
                     # an engine / structure switch after the cache grew: this form reads ONE view -- one copy of the cache.  (Not
                     # possible under a capture, nor for a graph captured ahead of a trigger, whose extent does not exist yet.)
-                    if torch.cuda.is_current_stream_capturing() or k_c.tokens + 256 * len(k_c.extents) < C:
+                    if torch.cuda.is_current_stream_capturing() or k_c.tokens + 256 * len(k_c.extents) < C or t_device is not None:
                         raise RuntimeError("decode_fused: this launch form cannot read a cache that grows by extents "
                                            "(MustafarConfig(extents=False), or consolidate() the arenas first)")
                     k_c, v_c = k_c.consolidate(), v_c.consolidate()
@@ -353,7 +364,8 @@ class MustafarAttention:
                     err = L.mustafar_decode_attention_view(st, k_c.view_ptr(), v_c.view_ptr(), *tail)
                 else:
                     err = L.mustafar_decode_attention_extents(st, k_c.view_ptr(), v_c.view_ptr(), k_c.tokens, k_c.ext_table.data_ptr(),
-                                                              v_c.ext_table.data_ptr(), *tail)
+                                                              v_c.ext_table.data_ptr(), *tail,
+                                                              t_device.data_ptr() if t_device is not None else None)
             elif use_arena:
                 err = L.mustafar_decode_attention_view(st, k_c.view_ptr(), v_c.view_ptr(), *tail)
             else:
@@ -361,6 +373,7 @@ class MustafarAttention:
                     st, p(k_c[0]) if C else None, p(k_c[2].flat) if C else None, p(k_c[1]) if C else None, p(k_c[3]) if C else None,
                     p(v_c[0]) if C else None, p(v_c[2].flat) if C else None, p(v_c[1]) if C else None, p(v_c[3]) if C else None, *tail)
         _lib.check(err, "mustafar_decode_attention")
+        C = C_used   # (the compressed length in use: `C` above was the capacity when t_device sizes the launch)
         if step_counter is not None:
             return out, (k_c, k_w, v_c, v_w, C, kv_seq_len - 1)   # lengths advance with the device counter
         k_w.len = v_w.len = w_len

@@ -160,3 +160,50 @@ def test_engine_switch_to_a_form_without_extents_consolidates():
         if i == 8:
             assert len(past[0].extents) == 1 and past[0].tokens == 256
     assert not past[0].extents and past[0].tokens == past[4] == 512
+
+
+def test_one_graph_serves_the_cache_through_two_triggers_with_device_side_T():
+    """`t_device` / `t_capacity`: the launch is sized for a capacity and reads the compressed tokens in use from device memory.  ONE
+    captured graph of the step is replayed across two 256-token triggers (run eagerly between replays: an extent each, 256 added
+    to the device T, 256 taken off the window counter); every checked step equals dense attention."""
+    from mustafar_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(9)
+    bsz, hq, hkv, D = 2, 8, 2, 128
+    L0 = 512 + R + 250                                         # first trigger at the 6th decode step, the second 256 steps later
+    K0, V0 = (torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(2))
+    attn = _attn(hq, hkv)
+    past = attn.to_fused(attn.build_cache(K0.clone(), V0.clone()))
+    C0, cap = past[4], past[4] + 512
+    t_dev = torch.tensor([C0], dtype=torch.int32, device=DEV)
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    q, k, v = (torch.zeros(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+    warm = (past[0], past[1].clone(), past[2], past[3].clone(), past[4], past[5])
+    attn.decode_fused(q, k, v, warm, step_counter=counter, t_device=t_dev, t_capacity=cap)    # scratch for the capacity, outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out, _ = attn.decode_fused(q, k, v, past, step_counter=counter, t_device=t_dev, t_capacity=cap)
+        _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream().cuda_stream, counter.data_ptr(), 1), "counter")
+    sig = (past[0].signature(), past[2].signature())
+    hk, hv = [K0], [V0]
+    state, since, triggers = past, 0, 0                        # host view of the cache: `state` advanced by `since` replays
+    for step in range(6 + 256 + 12):
+        qn, kn, vn = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+        hk.append(kn); hv.append(vn)
+        kv_len = state[5] + since + 1
+        if (kv_len - R - state[4]) % 256 == 0 and state[1].len + since + 1 >= 256:   # this step fires the trigger: eagerly
+            got, state = attn.decode(qn, kn, vn, attn.advance(state, since))
+            since, triggers = 0, triggers + 1
+            t_dev.add_(256)
+            counter.add_(1 - 256)                              # the eager step appended a row, the trigger slid the windows by 256
+            C_step = state[4] - 256                            # (the step itself still ran over the old compressed length)
+        else:
+            q.copy_(qn); k.copy_(kn); v.copy_(vn)
+            g.replay()
+            got, since, C_step = out, since + 1, state[4]
+        if step in (0, 4, 5, 6, 7, 150, 261, 262, 263, 273):
+            want = _dense(qn, torch.cat(hk, 2), torch.cat(hv, 2), C_step, 0.7, hq // hkv)
+            torch.testing.assert_close(got.float(), want, rtol=4e-3, atol=2e-3, msg=lambda m, step=step: f"step {step}: {m}")
+    assert triggers == 2 and state[4] == C0 + 512 == cap and len(state[0].extents) == 2
+    assert sig == (state[0].signature(), state[2].signature())

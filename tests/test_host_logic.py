@@ -70,8 +70,8 @@ def test_extent_arguments_are_validated_without_a_gpu():
     one = 8   # never dereferenced: validation fails first
     view = _lib.CacheView(one, one, one, one, 2 * 512, 2 * 512 + 1, 4096)
     nostride = _lib.CacheView(one, one, one, one, 2 * 512, 2 * 512 + 1, 0)
-    def call(kv, vv, T_base, kt, vt, T):
-        tail = (one, one, one, None, None, 1, 64, one, T + 64, one, one, 1, T, 8, 4, ctypes.c_float(11.3), None, None, 0, 0, 0)
+    def call(kv, vv, T_base, kt, vt, T, t_dev=None):
+        tail = (one, one, one, None, None, 1, 64, one, T + 64, one, one, 1, T, 8, 4, ctypes.c_float(11.3), None, None, 0, 0, 0, t_dev)
         return L.mustafar_decode_attention_extents(None, ctypes.byref(kv) if kv else None, ctypes.byref(vv) if vv else None, T_base, kt, vt, *tail)
     assert call(view, view, 500, one, one, 756) == 1          # T_base % 256
     assert call(view, view, 512, one, one, 512 + 128) == 1    # (T - T_base) % 256
@@ -79,6 +79,7 @@ def test_extent_arguments_are_validated_without_a_gpu():
     assert call(view, view, 512, None, one, 768) == 1         # tables missing
     assert call(nostride, view, 512, one, one, 768) == 1      # base views without a stream stride
     assert call(None, view, 512, one, one, 768) == 1
+    assert call(view, view, 512, one, one, 512, t_dev=one) == 1   # a device-side T needs a capacity beyond the base tokens
     assert L.mustafar_decode_reads_extents(4, 8256, 0) == 1 and L.mustafar_decode_reads_extents(8, 8256, 0) == 1
     assert L.mustafar_decode_reads_extents(1, 8256, 0) == 0 and L.mustafar_decode_reads_extents(2, 8256, 0) == 0    # G < 4 forms
     assert L.mustafar_decode_reads_extents(4, 8256 + 8, 0) == 0                                                  # row pitch % 32
