@@ -274,10 +274,13 @@ class Workload:
             return dt, (ku.value, vu.value, n.value)
         return dt, (self.timer.avg_us("key")[0], self.timer.avg_us("value")[0], len(self.timer.events["key"]))
 
-    def timed_graph(self, steps, warmup, start_at_trigger_distance=None):
+    def timed_graph(self, steps, warmup, start_at_trigger_distance=None, device_t=False):
         """The fused call sequence of a whole step (all layers) captured ONCE into a hipGraph and replayed per step;
         a device-side counter grows the windows between replays.  A step that fires the 256-token compression
-        trigger (model :324) runs eagerly and the graph is re-captured after it."""
+        trigger (model :324) runs eagerly; the graph of the steps behind it was captured ahead of it (the cache grows by extents:
+        nothing a graph holds moves).  device_t=True: ONE graph for the whole leg -- the launches are sized for a capacity and read
+        the compressed tokens in use from a device int (mustafar_decode_attention_extents: T_device); after the trigger step 256
+        are added to it and taken off the window counter."""
         from mustafar_amd import _lib
         attn, qs, ks, vs, layers, dev, lib = self.attn, self.qs, self.ks, self.vs, self.layers, self.dev, self.lib
         state = self.fused_state()
@@ -286,6 +289,14 @@ class Workload:
         attn.decode_fused(qs[0], ks[0], vs[0], warm[0])          # allocates the scratch buffers outside the capture
         torch.cuda.synchronize(dev)
         box = {"g": None, "since": 0, "triggers": 0, "next": None}
+        one_graph = device_t and all(hasattr(p[0], "extents") and p[0].tokens % 256 == 0 for p in state)
+        t_dev = torch.tensor([state[0][4]], dtype=torch.int32, device=dev) if one_graph else None
+        t_cap = state[0][4] + 256 * ((steps + warmup) // 256 + 2) if one_graph else None
+        kw_t = {"t_device": t_dev, "t_capacity": t_cap} if one_graph else {}
+        if one_graph:   # scratch sized for the capacity, outside the capture
+            attn.decode_fused(qs[0], ks[0], vs[0], (state[0][0], state[0][1].clone(), state[0][2], state[0][3].clone(), state[0][4], state[0][5]),
+                              step_counter=counter, **kw_t)
+            torch.cuda.synchronize(dev)
 
         def signature(st):   # addresses a captured graph holds: a re-housed arena or window makes the graph stale
             # (a cache that grows by extents keeps its base arrays and its extent table where they are: cache.py)
@@ -298,7 +309,7 @@ class Workload:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
                 for l in range(layers):
-                    attn.decode_fused(qs[l], ks[l], vs[l], st[l], step_counter=counter)
+                    attn.decode_fused(qs[l], ks[l], vs[l], st[l], step_counter=counter, **kw_t)
                 _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream(dev).cuda_stream, counter.data_ptr(), 1), "counter_add")
             return g
 
@@ -333,16 +344,22 @@ class Workload:
                 t1 = time.perf_counter()
                 box["triggers"] += 1
                 ahead = box["next"]
-                if ahead is not None and ahead[1] == signature(state):
+                if one_graph:          # the same graph goes on: 256 more tokens in use, the windows slid by 256 (the eager step appended one row)
+                    t_dev.add_(256)
+                    counter.add_(1 - 256)
+                    box["since"] = 0
+                    box["base"] = box.get("base", 0) + 1
+                elif ahead is not None and ahead[1] == signature(state):
                     counter.zero_()
                     box["g"], box["since"], box["next"] = ahead[0], 0, None
                 else:
                     capture()
                 torch.cuda.synchronize(dev)
                 self.extra.setdefault("trigger_step_ms", []).append((round((t1 - t0) * 1e3, 3), round((time.perf_counter() - t1) * 1e3, 3),
+                                                                     "same graph (device-side T)" if one_graph else
                                                                      "graph recorded ahead" if ahead is not None and box["g"] is ahead[0] else "re-captured"))
             else:
-                if box["next"] is None and until_trigger() == 8 and not self.no_capture_ahead:
+                if box["next"] is None and until_trigger() == 8 and not self.no_capture_ahead and not one_graph:
                     capture_ahead()
                 box["g"].replay()
                 box["since"] += 1
@@ -540,7 +557,12 @@ def main():
                 "triggers": w.extra.get("triggers_in_timed_region"),
                 "trigger_step_ms": w.extra.get("trigger_step_ms"),
                 "trigger_step_ms_note": "(eager decode step + prune/compress/append of 256 tokens per head and layer, switch to the graph of the longer cache), wall ms each; a replayed step is ms_per_step",
-                "note": "the trigger step runs eagerly (prune + compress + arena append of 256 tokens per head and layer); the graph of the steps behind it is recorded 8 steps ahead, between replays"}
+                "note": "the trigger step runs eagerly (prune + compress of 256 tokens per head and layer into an extent of the cache); the graph of the steps behind it is recorded 8 steps ahead, between replays"}
+        w.extra.pop("trigger_step_ms", None)
+        dt_1, _ = w.timed_graph(nst, 1, device_t=True)
+        trig["one_graph_device_side_T"] = {"value": round(world * w.batch * nst / dt_1, 2), "unit": "tokens/s", "ms_per_step": round(dt_1 / nst * 1e3, 4),
+                                           "triggers": w.extra.get("triggers_in_timed_region"), "trigger_step_ms": w.extra.get("trigger_step_ms"),
+                                           "note": "the same leg with ONE captured graph: the launches are sized for a capacity and read the compressed tokens in use from a device int (T_device); no capture behind the first"}
     alloc_peak = torch.cuda.max_memory_allocated(dev)
 
     # ---- the other BASELINE configs as sub-results (N = 1) -----------------------------------------------------------
