@@ -5,5 +5,5 @@ set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 NAME="$1"; shift
 mkdir -p "$ROOT/mustafar_amd/lib/variants"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -Wall -Wno-unused-function "$@" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function "$@" \
     -o "$ROOT/mustafar_amd/lib/variants/libmustafar_hip_$NAME.so" "$ROOT"/mustafar_amd/csrc/*.hip

@@ -106,7 +106,7 @@ def check(asm_text):
 def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "spmv.s")
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only",
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16", "--cuda-device-only",
                                "-S", "-I" + os.path.join(ROOT, "include"), SRC, "-o", out], stderr=subprocess.DEVNULL)
         hazards, loads, waits, stretches = check(open(out).read())
     print(f"scalar loads: {loads}, draining waits: {waits}, EXEC-masked stretches restored: {stretches}, hazards: {len(hazards)}")

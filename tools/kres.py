@@ -21,7 +21,7 @@ def demangle_short(name: str) -> str:
 
 def table(src: str, extra):
     with tempfile.TemporaryDirectory() as td:
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only", "-c", src,
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16", "--cuda-device-only", "-c", src,
                "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(td, "x.o")] + extra
         err = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None

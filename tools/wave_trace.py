@@ -23,7 +23,7 @@ def build_trace_lib():
     srcs = [os.path.join(ROOT, "mustafar_amd", "csrc", f) for f in ("spmv.hip", "compress.hip")]
     if os.path.exists(TRACE_LIB) and all(os.path.getmtime(TRACE_LIB) >= os.path.getmtime(s) for s in srcs):
         return
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16",
                            "-DMUSTAFAR_WAVE_TRACE", "-o", TRACE_LIB] + srcs)
 
 
