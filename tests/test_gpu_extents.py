@@ -207,3 +207,36 @@ def test_one_graph_serves_the_cache_through_two_triggers_with_device_side_T():
             torch.testing.assert_close(got.float(), want, rtol=4e-3, atol=2e-3, msg=lambda m, step=step: f"step {step}: {m}")
     assert triggers == 2 and state[4] == C0 + 512 == cap and len(state[0].extents) == 2
     assert sig == (state[0].signature(), state[2].signature())
+
+
+def test_left_padding_mask_across_a_trigger_with_extents():
+    """The hook's additive mask (models/llama_mustafar_kernel.py:293-301) over a cache that has grown by an extent: the columns of
+    the extent's tokens and of the window (behind ALL compressed tokens) line up with the mask; dense fp32 attention over the
+    unmasked columns is the reference."""
+    NEG = torch.finfo(torch.float16).min
+    torch.manual_seed(10)
+    bsz, hq, hkv, D = 3, 8, 2, 128
+    L0 = 256 + R + 252                                         # the trigger fires at the 4th decode step
+    pads = (0, 300, 530)                                       # row 1: inside the base, row 2: base and part of the extent
+    K0, V0 = (torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(2))
+    attn = _attn(hq, hkv)
+    past = attn.to_fused(attn.build_cache(K0.clone(), V0.clone()))
+    hk, hv = [K0], [V0]
+    for step in range(9):
+        qn, kn, vn = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+        hk.append(kn); hv.append(vn)
+        kv_len = past[5] + 1
+        mask = torch.zeros((bsz, 1, 1, kv_len), dtype=torch.float16, device=DEV)
+        for b, p in enumerate(pads):
+            mask[b, :, :, :p] = NEG
+        C_step = past[4]
+        out, past = attn.decode(qn, kn, vn, past, attention_mask=mask)
+        K_all, V_all = torch.cat(hk, 2), torch.cat(hv, 2)
+        K, V = K_all.clone(), V_all.clone()
+        K[:, :, :C_step] = torch.from_numpy(orc.prune_magnitude(K_all[:, :, :C_step].cpu().numpy(), 0.7)).to(DEV)
+        V[:, :, :C_step] = torch.from_numpy(orc.prune_magnitude(V_all[:, :, :C_step].cpu().numpy(), 0.7)).to(DEV)
+        s = torch.matmul(qn.float(), K.float().repeat_interleave(hq // hkv, dim=1).transpose(2, 3)) / math.sqrt(D)
+        s = s.masked_fill(mask < 0, float("-inf"))
+        want = torch.matmul(torch.softmax(s, -1), V.float().repeat_interleave(hq // hkv, dim=1))
+        torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3, msg=lambda m, step=step: f"step {step}: {m}")
+    assert past[4] == 512 and len(past[0].extents) == 1
