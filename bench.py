@@ -54,8 +54,8 @@ D, R = 128, 32
 API_NOTE = {
     "fused": "mustafar_decode_attention (C ABI extension), one call per layer; structure chosen by size: one-pass launch (key phase -> softmax step -> "
              "value phase per 64-token block, slabs merged per row) or key SpMV (+ window scores) -> softmax -> value SpMV (+ window p.V partials) -> sum",
-    "native": "the two reference entry points with un-padded (N=1) operands and a flat stream; PyTorch glue between them",
-    "reference": "exact reference call sequence: q/p zero-padded to 8 rows, torch.cat of per-head streams per call, 8-row outputs, PyTorch glue",
+    "native": "the two reference entry points (the compiled mustafar_package extension when built, else its ctypes mirror) with un-padded (N=1) operands and a flat stream; PyTorch glue between them",
+    "reference": "exact reference call sequence through the compiled mustafar_package extension (the module the reference hook imports; ctypes mirror if it is not built): q/p zero-padded to 8 rows, torch.cat of per-head streams per call, 8-row outputs, PyTorch glue",
 }
 
 

@@ -32,6 +32,30 @@ from . import _lib, compression, mustafar_package
 from .cache import CompressedArena
 
 
+def _operator_module():
+    """The module behind `mustafar_package.mustafar_{key,value}_formulation` in the unfused call sequences: the compiled PyTorch
+    extension of the reference's name (mustafar_amd/dropin, built by setup.py on the C ABI: what the reference hook imports,
+    ~5 us of host time per call) when it has been built, else the ctypes mirror (~12 us).  Same checks, same C-ABI calls."""
+    global _OPERATORS
+    if _OPERATORS is None:
+        import importlib.util, glob, os
+        _OPERATORS = mustafar_package
+        hits = glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin", "mustafar_package*.so"))
+        if hits and os.environ.get("MUSTAFAR_OPERATORS", "compiled") != "ctypes":
+            try:
+                _lib.load()   # (libmustafar_hip.so first: the extension links against it)
+                spec = importlib.util.spec_from_file_location("mustafar_package", hits[0])
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _OPERATORS = mod
+            except Exception:   # an extension built for another torch: the ctypes mirror does the same calls
+                _OPERATORS = mustafar_package
+    return _OPERATORS
+
+
+_OPERATORS = None
+
+
 @dataclass
 class MustafarConfig:
     num_attention_heads: int = 32
@@ -432,12 +456,12 @@ class MustafarAttention:
         if compressed_length != 0:
             if reference_api:
                 padded_query = F.pad(query_states.view(total_batch_size, -1, D), (0, 0, 0, 7), mode="constant", value=0)   # :273
-                att_compressed = mustafar_package.mustafar_key_formulation(
+                att_compressed = _operator_module().mustafar_key_formulation(
                     k_compressed[0], torch.cat(k_compressed[2]), k_compressed[1], k_compressed[3], padded_query,
                     compressed_length, D, total_batch_size, groups)                                    # :274
                 att_compressed = att_compressed[:, 0:1, :].view(bsz, self.num_heads, 1, compressed_length)   # :275
             else:
-                att_compressed = mustafar_package.mustafar_key_formulation(
+                att_compressed = _operator_module().mustafar_key_formulation(
                     k_compressed[0], k_compressed[2].flat, k_compressed[1], k_compressed[3],
                     query_states.reshape(total_batch_size, 1, D), compressed_length, D, total_batch_size, groups
                 ).view(bsz, self.num_heads, 1, compressed_length)
@@ -459,13 +483,13 @@ class MustafarAttention:
             if reference_api:
                 padded_score = F.pad(attn_weights[:, :, :, :compressed_length].view(total_batch_size, -1, compressed_length),
                                      (0, 0, 0, 7)).contiguous()                                        # :313
-                out_c = mustafar_package.mustafar_value_formulation(
+                out_c = _operator_module().mustafar_value_formulation(
                     v_compressed[0], torch.cat(v_compressed[2]), v_compressed[1], v_compressed[3], padded_score,
                     self._ws(query_states.device), D, compressed_length, total_batch_size, groups)     # :314
                 out_c = out_c[:, 0:1, :].view(bsz, self.num_heads, 1, D)                               # :315
             else:
                 score = attn_weights[:, :, :, :compressed_length].reshape(total_batch_size, 1, compressed_length)
-                out_c = mustafar_package.mustafar_value_formulation(
+                out_c = _operator_module().mustafar_value_formulation(
                     v_compressed[0], v_compressed[2].flat, v_compressed[1], v_compressed[3], score,
                     self._ws(query_states.device), D, compressed_length, total_batch_size, groups
                 ).view(bsz, self.num_heads, 1, D)
