@@ -77,6 +77,26 @@ __global__ __launch_bounds__(256) void k_lshr64(float* out, int iters, uint64_t*
     out[blockIdx.x * 256 + threadIdx.x] = (float)(dd0 + dd1);
     if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
 }
+#define MOV64x4 asm volatile("v_mov_b64 %0, %1\n v_mov_b64 %1, %0\n v_mov_b64 %0, %1\n v_mov_b64 %1, %0" : "+v"(dd0), "+v"(dd1));
+__global__ __launch_bounds__(256) void k_mov64(float* out, int iters, uint64_t* clk)   // 64 v_mov_b64 / iter (two registers each)
+{
+    unsigned long long dd0 = threadIdx.x * 0x9e3779b97f4a7c15ull, dd1 = ~dd0;
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) { REP8(MOV64x4 MOV64x4) }
+    uint64_t t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + threadIdx.x] = (float)(dd0 + dd1);
+    if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+}
+#define PKMOVx4 asm volatile("v_pk_mov_b32 %0, %1, %1\n v_pk_mov_b32 %1, %0, %0\n v_pk_mov_b32 %0, %1, %1\n v_pk_mov_b32 %1, %0, %0" : "+v"(dd0), "+v"(dd1));
+__global__ __launch_bounds__(256) void k_pkmov(float* out, int iters, uint64_t* clk)   // 64 v_pk_mov_b32 / iter
+{
+    unsigned long long dd0 = threadIdx.x * 0x9e3779b97f4a7c15ull, dd1 = ~dd0;
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) { REP8(PKMOVx4 PKMOVx4) }
+    uint64_t t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + threadIdx.x] = (float)(dd0 + dd1);
+    if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+}
 KERNEL(k_valu, REP8(V4 V4B))
 KERNEL(k_cvt, REP8(CVT4 CVT4))
 KERNEL(k_and, REP8(AND4 AND4))
@@ -130,7 +150,7 @@ int main()
      {"mbcnt(vgpr mask)", k_mbv, 64, 0}, {"lshl_add(vvv)", k_lshv, 64, 0}, {"cndmask(vcc)", k_cndv, 64, 0}, {"v_and(sgpr)", k_ands, 64, 0},
      {"v_bcnt", k_bcnt, 64, 0}, {"dot2(vvv)", k_dotv, 64, 0}, {"v_lshrrev_b32", k_lshr, 64, 0}, {"v_lshrrev_b64", k_lshr64, 64, 0},
      {"v_mul_f32(sgpr)", k_mulfs, 64, 0}, {"v_perm_b32", k_perm, 64, 0}, {"v_mad_u32_u24", k_mad24, 64, 0}, {"v_cmp->vcc", k_cmp, 64, 0},
-     {"v_readlane", k_readl, 64, 0}};
+     {"v_readlane", k_readl, 64, 0}, {"v_mov_b64", k_mov64, 64, 0}, {"v_pk_mov_b32", k_pkmov, 64, 0}};
     float* out; uint64_t* clk;
     const int iters = 2000;
     for (int wpc : {32}) {           // waves per CU (256-thread blocks -> 4 waves each)
