@@ -47,7 +47,13 @@ CONFIGS = {  # name: (label, Hq, Hkv, sparsity, L, batch)
     "c3": ("Llama-3-8B 70% L=8192 b8", 32, 8, 0.7, 8192, 8),
     "c4": ("Llama-3-8B 80% L=32768 b4", 32, 8, 0.8, 32768, 4),
     "c5": ("Mistral-7B 70% L=16384 b16", 32, 8, 0.7, 16384, 16),
+    # the metric's own axis (BASELINE.json.metric: Llama-3-8B, 70 %, seq_len 4k-32k; mem_spd_test.py:7-10, :72-74 fix the model and the
+    # sparsity and vary the length): c3's geometry and batch at the other three lengths -> `seq_sweep` in the bench line
+    "s4": ("Llama-3-8B 70% L=4096 b8", 32, 8, 0.7, 4096, 8),
+    "s16": ("Llama-3-8B 70% L=16384 b8", 32, 8, 0.7, 16384, 8),
+    "s32": ("Llama-3-8B 70% L=32768 b8", 32, 8, 0.7, 32768, 8),
 }
+SEQ_SWEEP = ("s4", "c3", "s16", "s32")
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
 D, R = 128, 32
 
@@ -70,6 +76,7 @@ def parse():
     ap.add_argument("--no-reference-api", action="store_true", help="skip the extra timings through the two reference entry points")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the c2/c4/c5 sub-results")
     ap.add_argument("--no-trigger-leg", action="store_true", help="skip the 256-step leg that contains a compression trigger")
+    ap.add_argument("--no-seq-sweep", action="store_true", help="skip the Llama-3-8B 70 % sweep over L = 4k / 16k / 32k (8k is the main result)")
     ap.add_argument("--no-graph", action="store_true", help="fused api without hipGraph capture of the step")
     ap.add_argument("--api", default="fused", choices=["fused", "native", "reference"], help="call sequence timed for `value`")
     return ap.parse_args()
@@ -277,6 +284,25 @@ class Workload:
         self.timer.enabled = False
         return dt, (self.timer.avg_us("key")[0], self.timer.avg_us("value")[0], len(self.timer.events["key"]))
 
+    def timed_unfused_graph(self, api, steps, warmup):
+        """The UNFUSED call sequence `api` ("reference": exactly the hook's -- 8-row pads, torch.cat of the per-head pieces, PyTorch glue,
+        the compiled mustafar_package extension; model :270-317) of a whole step, all layers, captured ONCE into a hipGraph and replayed:
+        what the drop-in boundary delivers with no Python between the launches.  The sequence reallocates its windows with torch.cat
+        every step (model :270, :309), so a captured step has ONE window length: the replays repeat that step (same shapes, same
+        inputs), which is what makes the replayed output checkable against the eager one, bit for bit."""
+        self.cfg.api, self.cfg.arena = api, False
+        state = list(self.pasts)
+        want = self.one_step(list(state))                    # eager (also warms allocator pools and the operator's workspace)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            got = self.one_step(list(state))
+        for _ in range(warmup):
+            g.replay()
+        dt = self.bracket(lambda: [g.replay() for _ in range(steps)])
+        same = all(torch.equal(a, b) for a, b in zip(got, want))
+        return dt, same
+
     def timed_graph(self, steps, warmup, start_at_trigger_distance=None, device_t=False):
         """The fused call sequence of a whole step (all layers) captured ONCE into a hipGraph and replayed per step;
         a device-side counter grows the windows between replays.  A step that fires the 256-token compression
@@ -462,6 +488,31 @@ def run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib):
     return out
 
 
+def run_seq_point(name, a, dev, rank, world, dist, rehearse, timer, lib):
+    """One point of the metric's axis (Llama-3-8B geometry, 70 % / 70 %, batch 8): fused + graph on the default engine, a few steps."""
+    w = Workload(name, a.layers, dev, rank, world, dist, rehearse, timer, lib)
+    excess = w.self_check()
+    if not excess <= 1.0:
+        raise SystemExit(f"bench.py: self-check FAILED at {name}: fused vs reference entry points, {excess:.2f}x the fp16 bound")
+    steps = max(3, a.steps // 2)
+    dt, (ku, vu, n) = w.timed_graph(steps, 2)
+    rl = w.roofline(ku, vu, n, traffic_file=False)
+    out = seq_point(w.L, w.T, world * w.batch * steps / dt, dt / steps * 1e3, steps, rl, w.extra, excess)
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
+def seq_point(L, T, tok_s, ms_step, steps, rl, extra, excess):
+    dense = extra.get("dense_bytes_at_measurement")
+    return {"seq_len": L, "compressed_tokens": T, "value": round(tok_s, 2), "unit": "tokens/s", "ms_per_step": round(ms_step, 4), "steps": steps,
+            "kernel": rl["kernel"], "kernel_us": rl["avg_launch_us"], "roofline_frac": rl["frac"], "roofline_achieved_GBps": rl["achieved"],
+            "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"],
+            "kv_bytes_in_use": extra.get("arena_bytes_in_use"), "kv_bytes_reserved": extra.get("arena_bytes_reserved"), "dense_kv_bytes": dense,
+            "kv_compression_ratio": round(dense / extra["arena_bytes_in_use"], 3) if dense and extra.get("arena_bytes_in_use") else None,
+            "self_check_excess": round(excess, 3)}
+
+
 def main():
     a = parse()
     world_env = os.environ.get("WORLD_SIZE")
@@ -528,6 +579,18 @@ def main():
             others[api] = {"value": round(world * w.batch * st_ / dt_o, 2), "unit": "tokens/s", "ms_per_step": round(dt_o / st_ * 1e3, 4),
                            "key_call_us": round(ku, 2), "value_call_us": round(vu, 2),
                            "note": API_NOTE[api] + ("; eager (no graph)" if api == "fused" else "")}
+        # the reference call sequence once more with the host out of the way: the whole 32-layer step as ONE replayed hipGraph
+        try:
+            st_ = max(2, a.steps // 2)
+            dt_g, same = w.timed_unfused_graph("reference", st_, 2)
+            others["reference_graph"] = {"value": round(world * w.batch * st_ / dt_g, 2), "unit": "tokens/s", "ms_per_step": round(dt_g / st_ * 1e3, 4),
+                                         "replayed_output_equals_eager": bool(same),
+                                         "note": API_NOTE["reference"] + "; the whole step captured once in a hipGraph (torch.cuda.graph around the unchanged "
+                                                 "hook code) and replayed: one window length, the same step repeated (INTEGRATION.md)"}
+            if not same:
+                raise SystemExit("bench.py: the replayed graph of the reference call sequence does not reproduce the eager step")
+        except RuntimeError as e:     # (a capture the allocator or an operator refuses is reported, not fatal: the eager legs stand)
+            others["reference_graph"] = {"value": None, "error": str(e)[:300]}
 
     # ---- the other two engines on the same call sequence and timed region, chosen per instance (MustafarConfig.engine -> the call's
     # `flags`): fma_mix = exact fp16 products (the round-1/2 default), mfma = the matrix pipe as a 4-wide FMA unit (opt-in; the
@@ -580,6 +643,18 @@ def main():
             if name != a.config:
                 sub[name] = run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib)
 
+    # ---- the metric's axis: Llama-3-8B geometry, 70 % / 70 %, batch 8 at L = 4k / 8k / 16k / 32k (N = 1) ------------------------
+    sweep = None
+    if world == 1 and not a.no_seq_sweep and a.api == "fused" and not a.no_graph and a.config == "c3":
+        pts = {}
+        for name in SEQ_SWEEP:
+            if name == "c3":    # the main result IS the 8k point
+                pts["8192"] = seq_point(L, T, world * batch * a.steps / dt, dt / a.steps * 1e3, a.steps, roofline, main_extra, excess)
+            else:
+                pts[str(CONFIGS[name][4])] = run_seq_point(name, a, dev, rank, world, dist, rehearse, timer, lib)
+        sweep = {"workload": "Llama-3-8B geometry (32 q / 8 kv heads, d 128, 32 layers), 70 % K / 70 % V, batch 8, fused entry point + hipGraph, default engine",
+                 "points": pts}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -622,7 +697,7 @@ def main():
         "allocator_note": "peak of the whole bench process: the reference-layout caches kept for the other call sequences and the self-check + "
                           "the appendable (arena) copy the timed fused leg runs on + transients",
         "roofline": roofline, "roofline_fma_mix": roofline_legs.get("valu"), "roofline_mfma": roofline_mfma, "cpu_baseline": cpu,
-        "other_call_sequences": others, "fma_engine_fma_mix": engine_legs.get("valu"), "fma_engine_mfma": engine_extra, "tokens_per_sec_incl_trigger": trig, "configs": sub,
+        "other_call_sequences": others, "fma_engine_fma_mix": engine_legs.get("valu"), "fma_engine_mfma": engine_extra, "tokens_per_sec_incl_trigger": trig, "seq_sweep": sweep, "configs": sub,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:

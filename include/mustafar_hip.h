@@ -93,8 +93,11 @@ int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int
 /*
  * Fused decode attention of one layer (extension).  Replaces the PyTorch glue of the reference hook
  * between the two SpMVs (models/llama_mustafar_kernel.py:270-317): window append, q.K_window^T, concat, / sqrt(d),
- * fp32 softmax, p.V_window, sum.  Four launches on `stream`: key SpMV (+ window scores) -> softmax -> value SpMV
- * (+ window p.V partials) -> sum of the partials.  All operands fp16 unless noted; B' = Batch_Size / num_key_value_groups.
+ * fp32 softmax, p.V_window, sum.  TWO launches on `stream` by default (T > 0): the one-pass launch -- every 64-token block runs key phase ->
+ * softmax step -> value phase, the dense window rides along as a few more workgroups, one slab (max, sum, unnormalised output) per
+ * workgroup and head -- and the row kernel that merges the slabs; MUSTAFAR_FLAG_TWO_LAUNCH (and T == 0) select the round-1 structure
+ * of four launches: key SpMV (+ window scores) -> softmax -> value SpMV (+ window p.V partials) -> sum of the partials.
+ * All operands fp16 unless noted; B' = Batch_Size / num_key_value_groups.
  *   q            [Batch_Size, 128]
  *   k_window     [B', window_capacity, 128]  rows [0, window_len) valid after the call; k_new [B', 128] (or NULL if the
  *   v_window     same                        newest row is already stored) is appended at row window_len - 1

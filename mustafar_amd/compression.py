@@ -11,7 +11,9 @@ The per-head tensors are views of one packed buffer (the reference clones each s
     torch.cat(list of all the pieces of one buffer, in order)      (model :274, :314: once per layer and decode step)
 returns that buffer itself instead of copying every head's stream again, and that the per-head concatenation of the trigger
     [torch.cat([old[b], new[b]], dim=0) for b in range(heads)]      (model :368, :390)
-lands, head by head, in ONE new buffer, so that the next `torch.cat` of the resulting list is free again.  Everything else a
+lands, head by head, in ONE new buffer, so that the next `torch.cat` of the resulting list is free again.  ALIASING: the result of
+the first form IS the cache's buffer, not a copy (an in-place op on it would change the cache; the reference hook only reads it), and
+a per-head concatenation asked for twice returns a fresh tensor the second time.  Everything else a
 piece is asked to do, it does as the plain tensor it is.  The hook's source is untouched by this: it is the tensors it gets back
 from `convert_*_batched` that know where they live.
 """
@@ -26,12 +28,13 @@ from . import _lib
 
 class _Backing:
     """One packed buffer and the pieces it is cut into: offs[b] .. offs[b + 1] (halfs) is head b's stream."""
-    __slots__ = ("buf", "offs", "indices", "succ", "__weakref__")
+    __slots__ = ("buf", "offs", "indices", "succ", "filled", "__weakref__")
 
     def __init__(self, buf: torch.Tensor, offs: List[int]):
         self.buf, self.offs = buf, offs
         self.indices = list(range(len(offs) - 1))
         self.succ = None     # (id of the other backing, backing that takes old + new per head): the trigger's concatenation target
+        self.filled = set()  # heads of THIS buffer already written by a trigger's per-head concatenation (see _append_piece)
 
 
 class StreamPiece(torch.Tensor):
@@ -73,6 +76,12 @@ def _append_piece(old: StreamPiece, new: StreamPiece) -> torch.Tensor:
             offs.append(offs[-1] + (ob.offs[i + 1] - ob.offs[i]) + (nb.offs[i + 1] - nb.offs[i]))
         ob.succ = (nb, _Backing(torch.empty((offs[-1],), dtype=ob.buf.dtype, device=ob.buf.device), offs))
     tgt = ob.succ[1]
+    if b in tgt.filled:
+        # the same concatenation asked for a second time: a fresh tensor, as torch.cat promises -- the slot of the shared buffer
+        # already belongs to the first result (which aliases the cache: INTEGRATION.md, "aliasing")
+        with torch._C.DisableTorchFunctionSubclass():
+            return torch.cat([old.as_subclass(torch.Tensor), new.as_subclass(torch.Tensor)], dim=0)
+    tgt.filled.add(b)
     dst = tgt.buf[tgt.offs[b]:tgt.offs[b + 1]]
     with torch._C.DisableTorchFunctionSubclass():
         torch.cat([old.as_subclass(torch.Tensor), new.as_subclass(torch.Tensor)], dim=0, out=dst)

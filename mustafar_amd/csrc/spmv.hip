@@ -1943,13 +1943,28 @@ __device__ __forceinline__ void coef4_issue_at(u32x4 (&c)[4], const void* __rest
 struct Gathered2 {
     uint32_t t[8];   // gathered halfs, EXACT zero where the tile has no element in the lane: even tiles bits 15:0, odd tiles bits 31:16
 };
-// rank and LDS address of tile j in address register k (four address registers and four scalar temporaries serve eight tiles)
+// Zeroing the gather registers (the masked gathers leave the lanes without an element untouched) is one full-rate v_mov_b32 per tile
+// -- 1 of the 6.5 vector instructions per tile of the dot2 loop, 1 of the 4.75 of the matrix-pipe loop.  MUSTAFAR_ZFILL = 1 lets the
+// LDS pipe do it instead: an UNMASKED ds_read_u16 from an address beyond the workgroup's LDS allocation (the tile's own address
+// register + 65534: out-of-range LDS reads return zero; LDS operations of a wave return in order, so the masked gather behind it lands
+// on top of the zeros).  Correct (the GPU suite passes with it) and 1 vector instruction per tile cheaper, but SLOWER: the gathers
+// already keep the CU's one LDS pipe busy a third of the launch, and a second LDS instruction per tile costs more than the v_mov it
+// saves (round 4, c3, kernel us: dot2 42.8 -> 43.4, matrix pipe 32.9 -> 36.0; c4 57.4 -> 63.5, c5 113.7 -> 121.6:
+// profiles/r04_probes.txt).  Off.
+#ifndef MUSTAFAR_ZFILL
+#define MUSTAFAR_ZFILL 0
+#endif
+#if MUSTAFAR_ZFILL
+#define MUSTAFAR_D2_ZERO(j, k) "ds_read_u16 %[t" #j "], %[x" #k "] offset:65534\n\t"
+#else
+#define MUSTAFAR_D2_ZERO(j, k) "v_mov_b32 %[t" #j "], 0\n\t"
+#endif
 #define MUSTAFAR_D2_RANK(j, k)                                              \
     "s_lshl2_add_u32 %[u" #k "], %[o" #j "], %[adj]\n\t"                     \
     "v_mbcnt_lo_u32_b32 %[x" #k "], %[l" #j "], 0\n\t"                        \
     "v_mbcnt_hi_u32_b32 %[x" #k "], %[h" #j "], %[x" #k "]\n\t"               \
     "v_lshl_add_u32 %[x" #k "], %[x" #k "], 1, %[u" #k "]\n\t"                \
-    "v_mov_b32 %[t" #j "], 0\n\t"
+    MUSTAFAR_D2_ZERO(j, k)
 #define MUSTAFAR_D2_LOAD(j, k) "s_mov_b64 exec, %[m" #j "]\n\tds_read_u16 %[t" #j "], %[x" #k "]\n\t"
 #define MUSTAFAR_D2_LOAD_HI(j, k) "s_mov_b64 exec, %[m" #j "]\n\tds_read_u16_d16_hi %[t" #j "], %[x" #k "]\n\t"
 // (EXEC contract as fma8 / gather8_clean: full wave at entry, restored before the statement ends)
@@ -2343,6 +2358,15 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_lean_kernel(
 #define MUSTAFAR_LP_WAVES 8
 #endif
 #define MUSTAFAR_LP_BOUNDS __launch_bounds__(kThreads, MUSTAFAR_LP_WAVES)
+// Issue priority by PROGRESS (pair form): s_setprio 1 while a wave is on its FIRST block, 0 afterwards.  The arbiter serves equal
+// priorities oldest wave first, so the workgroups dispatched first ran ahead and left (the first ones at 60 % of the launch's span)
+// while the youngest dragged on at falling occupancy; with this the laggards overtake whoever has reached a second block.
+// Measured (c3, kernel us, same box): dot2 45.3 -> 44.3, matrix pipe 35.5 -> 33.2; c4 76.1 -> 73.2 / 59.9 -> 57.3; c5 unchanged.  A level
+// per PHASE (3, 2, 1, 0) was slower on the vector engines (c3 46.9, c5 148.6 vs 139.5: strict least-progress-first lines the waves
+// up on memory) -- profiles/r04_probes.txt.  MUSTAFAR_PRIO=0: off (experiment builds).
+#ifndef MUSTAFAR_PRIO
+#define MUSTAFAR_PRIO 1
+#endif
 template <int ENG, bool EXT = false>   // EXT: the cache grew by extents (a.k_ext / a.v_ext / a.nb0); an instantiation of its own, so that
                                        // the plain launch does not carry the extra arguments (matrix-pipe form at c3: 37.6 vs 38.7 us)
 __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
@@ -2361,6 +2385,9 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     const int wrows = a.win_rows < 0 ? -a.win_rows : a.win_rows;   // window rows lead (win_rows > 0) or trail (< 0) the grid
     const int wy = a.win_rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
     if (wy >= 0 && wy < wrows) {   // dense window
+#ifdef MUSTAFAR_WIN_PRIO   // experiment: the window workgroups (short latency chains dispatched behind the SpMV rows) at a high issue priority
+        __builtin_amdgcn_s_setprio(MUSTAFAR_WIN_PRIO);
+#endif
         const int task = wy * gridDim.x + blockIdx.x;
         if (task < (int)(gridDim.y - wrows) * a.nchunks) {
             int T_used = -1;
@@ -2458,6 +2485,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     for (int h = 0; h < G; h++) acc[h] = 0.f;
     m_run[0] = m_run[1] = -INFINITY;
     l_run[0] = l_run[1] = 0.f;
+    if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     for (int t = tb0; t < tb_end; t += kWaves / 2) {   // workgroup-uniform: every wave reaches the barriers below
         const int tb = t + pair;
@@ -2521,6 +2549,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
             prefetch_done(pfv);
         }
         MUSTAFAR_PTRACE_STAMP(5);
+        if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(0);   // (the first block is done)
     }
     if (a.pair_slabs) {
         // ---- a slab per pair: each wave stores its output half as it holds it and the (maximum, sum) of its two heads -- no exchange, no
@@ -2570,9 +2599,10 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
 
 inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : 1; }
 
-// FMA engine of the G = 4 kernels: 0 = VALU (v_fma_mix_f32; default, MFMA left off as the north_star asks),
-// 1 = matrix pipe as a 4-wide FMA unit (v_mfma_f32_4x4x4_16B_f16; opt-in: MUSTAFAR_FMA_ENGINE=mfma or
-// mustafar_set_fma_engine(1)).
+// FMA engine of the G = 4 kernels: 2 = v_dot2_f32_f16 on pairs of tiles (the DEFAULT: one-pass launch only; the two reference
+// entry points and every G < 4 kernel then run v_fma_mix), 0 = v_fma_mix_f32 everywhere (exact fp16 products, subnormals
+// included; MUSTAFAR_FMA_ENGINE=valu), 1 = matrix pipe as a 4-wide FMA unit (v_mfma_f32_4x4x4_16B_f16; opt-in, MFMA left off by
+// default as the north_star asks: MUSTAFAR_FMA_ENGINE=mfma or mustafar_set_fma_engine(1)).
 inline int fma_engine();
 int g_key_split = -1;   // 0 = automatic; MUSTAFAR_KEY_SPLIT=1|2 forces
 inline int key_split(int ntb, int gy)

@@ -6,6 +6,7 @@
 #include <torch/extension.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 
 #include <map>
 #include <mutex>
@@ -88,7 +89,12 @@ torch::Tensor mustafar_value_formulation(torch::Tensor bmp, torch::Tensor NZ, to
     // fp32 partial slabs: one buffer per (device, stream) -- launches of a stream run in order and may share it; different
     // streams (or threads on different streams) never share slabs
     void* ws = nullptr;
-    if (need > 0) {
+    torch::Tensor captured_ws;   // under a graph capture the slabs come from the capture's own pool (the graph keeps them for its
+                                 // replays; a buffer cached here across captures could outlive the pool it came from)
+    if (need > 0 && c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None) {
+        captured_ws = torch::empty({need}, torch::TensorOptions().dtype(torch::kUInt8).device(B.device()));
+        ws = captured_ws.data_ptr();
+    } else if (need > 0) {
         auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
         static std::mutex mu;
         static std::map<std::pair<int, void*>, torch::Tensor> slabs;

@@ -316,8 +316,8 @@ class MustafarAttention:
         per step); the host-side lengths/`kv_seq_len` of the returned `past` then describe the FIRST replay and the
         256-token trigger is the caller's business (see bench.py).
 
-        `t_device` (int32 device tensor) + `t_capacity`: the compressed tokens IN USE as a device quantity and the capacity the
-        launch is sized for (a cache that grows by extents only).  ONE captured graph of the call then serves every compressed
+        `t_device` (int32 device tensor) + `t_capacity` (graph replay only: `step_counter` is required with them): the compressed
+        tokens IN USE as a device quantity and the capacity the launch is sized for (a cache that grows by extents only).  ONE captured graph of the call then serves every compressed
         length up to `t_capacity`: after a trigger (run eagerly, outside the graph) the caller adds 256 to `t_device` and takes
         256 off `step_counter` (tests/test_gpu_extents.py)."""
         cfg = self.cfg
@@ -327,6 +327,8 @@ class MustafarAttention:
         k_c, k_w, v_c, v_w, C, _ = self.to_fused(past)
         C_used = C
         if t_device is not None:   # the launch is sized for the capacity; the kernels read the tokens in use from `t_device`
+            if step_counter is None:
+                raise ValueError("decode_fused: t_device is for captured graphs and needs step_counter (an eager call passes neither)")
             if t_capacity is None or t_capacity < C or (t_capacity - C) % 256 or not isinstance(k_c, CompressedArena) or t_capacity <= k_c.tokens:
                 raise ValueError("decode_fused: t_device needs an arena cache and t_capacity = compressed length + a multiple of 256, beyond the base tokens")
             C = t_capacity

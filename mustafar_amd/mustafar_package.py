@@ -93,6 +93,8 @@ _workspaces = {}   # (device, stream) -> slab buffer
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     """fp32 partial slabs, one buffer per (device, STREAM): launches of one stream run in order, so they may share it;
     two streams (or threads on different streams) never see each other's slabs -- a process-wide buffer did."""
+    if torch.cuda.is_current_stream_capturing():   # a capture takes its slabs from its own pool (the graph keeps them for its replays)
+        return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:

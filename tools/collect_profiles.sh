@@ -3,9 +3,10 @@
 #   TCC traffic (c3), bench line (driver form), rocprofv3 kernel stats of the same command, SQ counters of the one-pass launch
 #   per engine (c3, c5), mem_spd harness, prefill-compression and append timings, the two reference entry points, launch
 #   structures, the cost of a trigger that adds an extent.
-# Every profiler pass starts from an empty directory and keeps its output in a .err file; a failing step stops the script (set -e),
-# so nothing stale can be copied into profiles/ and a fault under the profiler does not go unnoticed.
-set -e
+# Every profiler pass starts from an empty directory and keeps its output in a .err file; a failing step -- a program that dies in
+# front of a `| grep` included (pipefail) -- stops the script, so nothing stale or truncated can be copied into profiles/ and a fault
+# under the profiler does not go unnoticed.
+set -e -o pipefail
 TAG=${1:-r03}; R=$(pwd); O=$R/gpurun_out/$TAG; rm -rf "$O"; mkdir -p "$O"
 one_csv() { local n; n=$(ls $1 2>/dev/null | wc -l); [ "$n" = "1" ] || { echo "expected exactly one file for $1, found $n"; exit 1; }; ls $1; }
 
@@ -20,7 +21,8 @@ cp $(one_csv "$O/rocprof_bench/*/*kernel_stats.csv") $O/bench_c3_kernel_stats.cs
 
 for E in dot2 valu mfma; do
   PROF_FUSED=1 MUSTAFAR_FMA_ENGINE=$E tools/prof_pmc.sh ${TAG}_${E}_c3 c3 > /dev/null
-  grep -v "spmv_kernel\|^$" gpurun_out/pmc_${TAG}_${E}_c3.txt > $O/pmc_sq_c3_${E}_onepass.txt || true
+  grep -v "spmv_kernel\|^$" gpurun_out/pmc_${TAG}_${E}_c3.txt > $O/pmc_sq_c3_${E}_onepass.txt
+  [ -s $O/pmc_sq_c3_${E}_onepass.txt ] || { echo "empty counter summary for engine $E"; exit 1; }
   PROF_FUSED=1 MUSTAFAR_FMA_ENGINE=$E tools/prof_pmc.sh ${TAG}_${E}_c5 c5 > /dev/null
   cp gpurun_out/pmc_${TAG}_${E}_c5.txt $O/pmc_sq_c5_${E}.txt
 done; echo "pmc done"

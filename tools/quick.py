@@ -3,7 +3,8 @@
 
     python tools/quick.py --cfg c3 c5 --set valu dot2 mfma valu:lean=0 valu:onepass=0 dot2:tbw=2
 
-A setting is engine[:key=value...] with engine in valu | dot2 | mfma and keys onepass (0 | 1 | 2), lean (0 | 1), tbw, wgs.
+A setting is engine[:key=value...] with engine in valu | dot2 | mfma and keys onepass (0 | 1 | 2), lean (0 | 1), tbw, wgs,
+winlast, pslab.
 Per setting: self-check against the two reference entry points, then the step replayed as a graph (tokens/s) and the
 kernels' own durations.  One line per (config, setting)."""
 import argparse
