@@ -53,6 +53,8 @@ CONFIGS = {  # name: (label, Hq, Hkv, sparsity, L, batch)
     "s16": ("Llama-3-8B 70% L=16384 b8", 32, 8, 0.7, 16384, 8),
     "s32": ("Llama-3-8B 70% L=32768 b8", 32, 8, 0.7, 32768, 8),
 }
+CONFIGS["m8"] = ("Llama-2-7B (MHA) 70% L=8192 b8 [tools only]", 32, 32, 0.7, 8192, 8)
+CONFIGS["g2"] = ("GQA-2 (32 q / 16 kv heads) 70% L=8192 b8 [tools only]", 32, 16, 0.7, 8192, 8)
 SEQ_SWEEP = ("s4", "c3", "s16", "s32")
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
 D, R = 128, 32

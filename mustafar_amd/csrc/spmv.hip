@@ -1940,6 +1940,18 @@ __device__ __forceinline__ void coef4_issue_at(u32x4 (&c)[4], const void* __rest
                  : "s"(base), "i"(OFF), "i"(OFF + HS), "i"(OFF + 2 * HS), "i"(OFF + 3 * HS));
 }
 
+template <int G, int OFF, int HS>
+__device__ __forceinline__ void coef_issue_at(u32x4 (&c)[G], const void* __restrict__ base)
+{
+    if constexpr (G == 4) {
+        coef4_issue_at<OFF, HS>(c, base);
+    } else if constexpr (G == 2) {
+        asm volatile("s_load_dwordx4 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4" : "=&s"(c[0]), "=&s"(c[1]) : "s"(base), "i"(OFF), "i"(OFF + HS));
+    } else {
+        asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(c[0]) : "s"(base), "i"(OFF));
+    }
+}
+
 struct Gathered2 {
     uint32_t t[8];   // gathered halfs, EXACT zero where the tile has no element in the lane: even tiles bits 15:0, odd tiles bits 31:16
 };
@@ -2089,48 +2101,53 @@ __device__ __forceinline__ uint32_t prefetch_meta_all(const uint64_t* __restrict
 // One staged chunk (32 tiles) of the lean kernel; the step schedule is chunk32's.
 //   bmp_t / idx_t : the BLOCK's bitmaps / offsets (the chunk starts TOFF tiles in);  cbase + COFF + h * HS : the chunk's first
 //   coefficient of head h
-template <int ENG, int TOFF, int COFF, int HS>
+template <int ENG, int TOFF, int COFF, int HS, int G = 4>
 __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
-                                           const void* __restrict__ cbase, float (&acc)[4])
+                                           const void* __restrict__ cbase, float (&acc)[G])
 {
+    static_assert(G == 4 || ENG == 0, "dot2 pairs four heads' coefficients; G < 4 runs v_fma_mix");
     // (with the coefficients in scalar registers as well, an early request leaves the loop 140+ registers short of the 78 a wave of
     // this launch has, and the compiler then spills registers that loads are still writing: tools/check_smem_hazards.py)
     constexpr bool kEarly = MUSTAFAR_META_EARLY > 1;
     MetaB cur, nxt;
-    u32x4 c[4];
+    u32x4 c[G];
     metab_issue_at<TOFF>(cur, bmp_t, idx_t);
-    coef4_issue_at<COFF, HS>(c, cbase);
+    coef_issue_at<G, COFF, HS>(c, cbase);
     metab_wait(cur);
 #define MUSTAFAR_STEP(S)                                        \
     if constexpr (kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t); \
     if constexpr (ENG == 2) {                                   \
-        Gathered2 g;                                            \
-        gather8_d2(cur, adj, g);                                \
-        gather2_wait(g, c);                                     \
-        if constexpr (!kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
-        fma8_d2(c, g, acc);                                     \
+        if constexpr (G == 4) {                                 \
+            Gathered2 g;                                        \
+            gather8_d2(cur, adj, g);                            \
+            gather2_wait(g, c);                                 \
+            if constexpr (!kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
+            fma8_d2(c, g, acc);                                 \
+        }                                                       \
     } else {                                                    \
         Gathered g;                                             \
         gather8(cur, adj, g);                                   \
-        gather_wait<4>(g, c);                                   \
+        gather_wait<G>(g, c);                                   \
         if constexpr (!kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
-        fma8<4>(c, g, acc);                                     \
+        fma8<G>(c, g, acc);                                     \
     }                                                           \
     if constexpr (kEarly) metab_ready(nxt); else metab_wait(nxt); \
-    coef4_issue_at<COFF + 16 * (S + 1), HS>(c, cbase);          \
+    coef_issue_at<G, COFF + 16 * (S + 1), HS>(c, cbase);        \
     cur = nxt;
     MUSTAFAR_STEP(0) MUSTAFAR_STEP(1) MUSTAFAR_STEP(2)
 #undef MUSTAFAR_STEP
     if constexpr (ENG == 2) {
-        Gathered2 g;
-        gather8_d2(cur, adj, g);
-        gather2_wait(g, c);
-        fma8_d2(c, g, acc);
+        if constexpr (G == 4) {
+            Gathered2 g;
+            gather8_d2(cur, adj, g);
+            gather2_wait(g, c);
+            fma8_d2(c, g, acc);
+        }
     } else {
         Gathered g;
         gather8(cur, adj, g);
-        gather_wait<4>(g, c);
-        fma8<4>(c, g, acc);
+        gather_wait<G>(g, c);
+        fma8<G>(c, g, acc);
     }
 }
 
@@ -2139,18 +2156,23 @@ __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restr
 //   VAL = true  (value): chunks 0, 1 -> accA (channels 0..63), chunks 2, 3 -> accB (channels 64..127), lane = channel;
 //                        coefficient of a tile: the row's half (token % 64)
 //   bnd: the block's five chunk bounds (bnd_load), fetched by the caller ahead of time
-template <int ENG, int HS, bool VAL, int CB, int CN>   // chunks [CB, CB + CN) of the block
+template <int ENG, int HS, bool VAL, int CB, int CN, int G = 4>   // chunks [CB, CB + CN) of the block; G heads (G < 4: ENG 0)
 __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t lds_addr, const uint64_t* __restrict__ bmp_t,
                                                  const uint32_t* __restrict__ idx_t, const unsigned char* __restrict__ nz_h,
-                                                 const void* __restrict__ cbase, uint32_t bnd, int lane, float (&accA)[4],
-                                                 float (&accB)[4]
+                                                 const void* __restrict__ cbase, uint32_t bnd, int lane, float (&accA)[G],
+                                                 float (&accB)[G]
 #ifdef MUSTAFAR_WAVE_TRACE
                                                  , PhaseTrace& phase_trace_
 #endif
                                                  , uint32_t ctab_lane = 0   // ENG == 1: the LDS coefficient table (cbase unused)
                                                  )
 {
-    f32x4 mA = {accA[0], accA[1], accA[2], accA[3]}, mB = {accB[0], accB[1], accB[2], accB[3]};   // (ENG == 1 only)
+    f32x4 mA = {0.f, 0.f, 0.f, 0.f}, mB = {0.f, 0.f, 0.f, 0.f};   // (ENG == 1 only)
+    if constexpr (ENG == 1) {
+        static_assert(ENG != 1 || G == 4, "the matrix-pipe engine multiplies four heads at a time");
+#pragma unroll
+        for (int h = 0; h < G; h++) { mA[h] = accA[h]; mB[h] = accB[h]; }
+    }
     uint32_t i0 = bnd_get(bnd, CB);
     const uint32_t len0 = 4u * (bnd_get(bnd, CB + 1) - i0);
     Stage st = stage_issue(nz_h + 4ull * i0, len0, lane);
@@ -2179,10 +2201,10 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
             else if (c == 2) chunk32_mfma_at<64, VAL ? 0 : 128>(adj, bmp_t, idx_t, ctab_lane, VAL ? mB : mA);
             else             chunk32_mfma_at<96, VAL ? 64 : 192>(adj, bmp_t, idx_t, ctab_lane, VAL ? mB : mA);
         } else {
-            if (c == 0)      chunk32_at<ENG, 0, 0, HS>(adj, bmp_t, idx_t, cbase, accA);
-            else if (c == 1) chunk32_at<ENG, 32, 64, HS>(adj, bmp_t, idx_t, cbase, accA);
-            else if (c == 2) chunk32_at<ENG, 64, VAL ? 0 : 128, HS>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
-            else             chunk32_at<ENG, 96, VAL ? 64 : 192, HS>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
+            if (c == 0)      chunk32_at<ENG, 0, 0, HS, G>(adj, bmp_t, idx_t, cbase, accA);
+            else if (c == 1) chunk32_at<ENG, 32, 64, HS, G>(adj, bmp_t, idx_t, cbase, accA);
+            else if (c == 2) chunk32_at<ENG, 64, VAL ? 0 : 128, HS, G>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
+            else             chunk32_at<ENG, 96, VAL ? 64 : 192, HS, G>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
         }
         __builtin_amdgcn_wave_barrier();
         if (c < CB + CN - 1) {
@@ -2193,11 +2215,11 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
     if constexpr (ENG == 1) {   // (the pair form passes the same array for accA and accB: only the one its chunks went to is written)
         if (CB < 2 || !VAL) {
 #pragma unroll
-            for (int h = 0; h < 4; h++) accA[h] = mA[h];
+            for (int h = 0; h < G; h++) accA[h] = mA[h];
         }
         if (VAL && CB + CN > 2) {
 #pragma unroll
-            for (int h = 0; h < 4; h++) accB[h] = mB[h];
+            for (int h = 0; h < G; h++) accB[h] = mB[h];
         }
     }
 }
@@ -2367,7 +2389,8 @@ __global__ __launch_bounds__(kThreads) void decode_onepass_lean_kernel(
 #ifndef MUSTAFAR_PRIO
 #define MUSTAFAR_PRIO 1
 #endif
-template <int ENG, bool EXT = false>   // EXT: the cache grew by extents (a.k_ext / a.v_ext / a.nb0); an instantiation of its own, so that
+template <int ENG, bool EXT = false, int G = 4>   // G: q-heads per kv-head served by one pass (4, 2 or 1; G < 4 runs the v_fma_mix engine);
+                                                // EXT: the cache grew by extents (a.k_ext / a.v_ext / a.nb0); an instantiation of its own, so that
                                        // the plain launch does not carry the extra arguments (matrix-pipe form at c3: 37.6 vs 38.7 us)
 __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     const uint64_t* __restrict__ k_bmp, const unsigned char* __restrict__ k_nz, const uint32_t* __restrict__ k_idx,
@@ -2375,7 +2398,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     const uint32_t* __restrict__ v_idx, const uint32_t* __restrict__ v_nz_off, OneArgs a, int64_t k_bmp_stride,
     int64_t k_idx_stride, uint32_t k_nz_stride, int64_t v_bmp_stride, int64_t v_idx_stride, uint32_t v_nz_stride)
 {
-    constexpr int G = 4;
+    static_assert(G == 4 || ENG == 0, "dot2 and the matrix pipe work on four heads; G < 4 runs v_fma_mix");
+    constexpr int HW = G >= 2 ? G / 2 : 1;   // heads a wave of the pair finishes in the softmax step (G = 1: the even wave its one head, the odd wave none)
     // matrix-pipe engine: behind the stage windows, the q rows of the four heads ([4][kKeyTabStride]) and one e table per pair ([4][kValTabStride])
     constexpr int kTabBytes = ENG == 1 ? 4 * kKeyTabStride + 2 * 4 * kValTabStride : 0;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes + 2 * G * 4];   // (+ the pairs' rescale factors)
@@ -2398,7 +2422,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         return;
     }
     const int by = blockIdx.y - (a.win_rows > 0 ? a.win_rows : 0);
-    const int hb_per_kv = a.groups >> 2;
+    const int hb_per_kv = a.groups / G;
     const int kvh = hb_per_kv == 1 ? by : by / hb_per_kv;
     const int bh0 = kvh * a.groups + (by - kvh * hb_per_kv) * G;
     const int ntb_cap = a.T >> 6;   // what the launch was sized for
@@ -2413,8 +2437,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
                 const int64_t slab = (int64_t)blockIdx.x * nsl + sl;
                 // (every thread stores, some the same bytes: no divergent region around the block loop's EXEC-owning asm statements)
                 float* so = a.ws_o + (slab * a.BH + bh0) * kD;
-                so[threadIdx.x] = 0.f;
-                so[kThreads + threadIdx.x] = 0.f;
+#pragma unroll
+                for (int o = 0; o < G * kD; o += kThreads) so[o + (threadIdx.x & (G * kD - 1) & (kThreads - 1))] = 0.f;   // (G = 1: 128 floats, stored twice)
                 *reinterpret_cast<float2*>(a.ws_ml + (slab * a.BH + bh0 + (threadIdx.x & (G - 1))) * 2) = make_float2(-INFINITY, 0.f);
             }
             MUSTAFAR_PTRACE_END(7);
@@ -2465,7 +2489,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     float* xch_out = reinterpret_cast<float*>(lds);                                           // [2][64] partial scores for the partner
     const float* xch_in = reinterpret_cast<const float*>(smem + (wave ^ 1) * kStageBytes);    // the partner's, for my two heads
     float* alf = reinterpret_cast<float*>(smem + kWaves * kStageBytes + kTabBytes) + pair * G;
-    const int h0 = odd ? 2 : 0;   // my heads: h0, h0 + 1; the partner's: 2 - h0, 3 - h0
+    const int h0 = (odd && G >= 2) ? HW : 0;   // my heads: h0 .. h0 + HW - 1 (G = 4: two, G = 2: one; G = 1: the even wave's head 0, the odd wave has none)
+    const bool has_heads = G >= 2 || !odd;
     constexpr float kEScaleLog2 = ENG == 2 ? 15.f : 0.f;
 
     uint32_t ctab_q = 0, ctab_e = 0;
@@ -2480,11 +2505,11 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         ctab_q = (uint32_t)reinterpret_cast<uintptr_t>(tab) + (lane & 3) * kKeyTabStride;
         ctab_e = (uint32_t)reinterpret_cast<uintptr_t>(ptab) + (lane & 3) * kValTabStride;
     }
-    float m_run[2], l_run[2], acc[G];   // acc: the wave's output half (even: channels 0..63, odd: 64..127), four heads; m_run, l_run: my two heads
+    float m_run[HW], l_run[HW], acc[G];   // acc: the wave's output half (even: channels 0..63, odd: 64..127), four heads; m_run, l_run: my two heads
 #pragma unroll
     for (int h = 0; h < G; h++) acc[h] = 0.f;
-    m_run[0] = m_run[1] = -INFINITY;
-    l_run[0] = l_run[1] = 0.f;
+#pragma unroll
+    for (int j = 0; j < HW; j++) { m_run[j] = -INFINITY; l_run[j] = 0.f; }
     if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     for (int t = tb0; t < tb_end; t += kWaves / 2) {   // workgroup-uniform: every wave reaches the barriers below
@@ -2496,7 +2521,9 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         const uint64_t* vbt = vb + (int64_t)tbc * kTilesPerTb;
         const uint32_t* vit = vi + (int64_t)tbc * kTilesPerTb;
         h16* eblk = eb + (int64_t)tbc * (G * 64);
-        float s[G], alpha[G], own[2] = {0.f, 0.f};   // own: the partial scores of my two heads
+        float s[G], alpha[G], own[HW];   // own: the partial scores of my heads
+#pragma unroll
+        for (int j = 0; j < HW; j++) own[j] = 0.f;
 #pragma unroll
         for (int h = 0; h < G; h++) { s[h] = 0.f; alpha[h] = 1.f; }
         uint32_t bnd_v = 0, pfv = 0;
@@ -2505,8 +2532,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
             const uint32_t bnd_k = bnd_load(kit, lane);
             const uint32_t pfk = odd ? prefetch_meta_all<64, 64>(kbt, kit, lane) : prefetch_meta_all<0, 64>(kbt, kit, lane);   // (the wave's own half)
             if (mrow) mk = mrow[tb * 64 + lane];
-            if (odd) lean_block_phase<ENG, kD * 2, false, 2, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG, ctab_q);
-            else     lean_block_phase<ENG, kD * 2, false, 0, 2>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG, ctab_q);
+            if (odd) lean_block_phase<ENG, kD * 2, false, 2, 2, G>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG, ctab_q);
+            else     lean_block_phase<ENG, kD * 2, false, 0, 2, G>(lds, lds_addr, kbt, kit, kn, qb, bnd_k, lane, s, s MUSTAFAR_PTRACE_ARG, ctab_q);
             prefetch_done(pfk);
             // the value side's chunk bounds and metadata lines are requested HERE, a barrier and a softmax step (~2 us) in front of
             // their use: requested at the block's start (~10 us ahead) the lines were often gone from L2 again by the time the
@@ -2514,15 +2541,23 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
             bnd_v = bnd_load(vit, lane);
             pfv = odd ? prefetch_meta_all<64, 64>(vbt, vit, lane) : prefetch_meta_all<0, 64>(vbt, vit, lane);
             // (static indices under a wave-uniform branch: `s[odd ? 0 : 2]` would move the array to scratch memory)
-            if (odd) { xch_out[lane] = s[0]; xch_out[64 + lane] = s[1]; own[0] = s[2]; own[1] = s[3]; }
-            else     { xch_out[lane] = s[2]; xch_out[64 + lane] = s[3]; own[0] = s[0]; own[1] = s[1]; }
+            if constexpr (G == 4) {
+                if (odd) { xch_out[lane] = s[0]; xch_out[64 + lane] = s[1]; own[0] = s[2]; own[1] = s[3]; }
+                else     { xch_out[lane] = s[2]; xch_out[64 + lane] = s[3]; own[0] = s[0]; own[1] = s[1]; }
+            } else if constexpr (G == 2) {
+                if (odd) { xch_out[lane] = s[0]; own[0] = s[1]; }
+                else     { xch_out[lane] = s[1]; own[0] = s[0]; }
+            } else {
+                if (odd) xch_out[lane] = s[0];       // (G = 1: the even wave finishes the head)
+                else     own[0] = s[0];
+            }
         }
         MUSTAFAR_PTRACE_STAMP(2);
         __syncthreads();
-        if (active) {
-            float al[2];
+        if (active && has_heads) {
+            float al[HW];
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < HW; j++) {
                 float x = scaled((h16)(own[j] + xch_in[j * 64 + lane]), a.inv_sqrt_d);   // (even + odd in either wave: the same sum)   // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
                 if (mrow) x = masked(x, mk);
                 const float m_new = uniform_f(fmaxf(m_run[j], wave_max(x)));
@@ -2533,7 +2568,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
                 l_run[j] = uniform_f(l_run[j] * al[j] + wave_sum((float)e));
                 m_run[j] = m_new;
             }
-            if (lane < 2) alf[h0 + lane] = lane ? al[1] : al[0];
+            if constexpr (HW == 2) { if (lane < 2) alf[h0 + lane] = lane ? al[1] : al[0]; }
+            else                   { if (lane < 1) alf[h0] = al[0]; }
             if constexpr (ENG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my e stores have reached L2 before the pair's scalar loads
         }
         __syncthreads();
@@ -2544,8 +2580,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
 #pragma unroll
             for (int h = 0; h < G; h++) acc[h] *= alpha[h];
             // (the partner read my outgoing partial scores before the barrier above; my value phase now rewrites the window)
-            if (odd) lean_block_phase<ENG, 64 * 2, true, 2, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
-            else     lean_block_phase<ENG, 64 * 2, true, 0, 2>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
+            if (odd) lean_block_phase<ENG, 64 * 2, true, 2, 2, G>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
+            else     lean_block_phase<ENG, 64 * 2, true, 0, 2, G>(lds, lds_addr, vbt, vit, vn, eblk, bnd_v, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
             prefetch_done(pfv);
         }
         MUSTAFAR_PTRACE_STAMP(5);
@@ -2559,9 +2595,9 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         float* so = a.ws_o + (slab * a.BH + bh0) * kD + (odd ? 64 : 0) + lane;
 #pragma unroll
         for (int h = 0; h < G; h++) so[h * kD] = acc[h] * kOut;
-        if (lane < 2)   // (maximum, sum) of my two heads
+        if (has_heads && lane < HW)   // (maximum, sum) of my heads
             *reinterpret_cast<float2*>(a.ws_ml + (slab * a.BH + bh0 + h0 + lane) * 2) =
-                make_float2(lane ? m_run[1] : m_run[0], (lane ? l_run[1] : l_run[0]) * kOut);
+                make_float2(lane ? m_run[HW - 1] : m_run[0], (lane ? l_run[HW - 1] : l_run[0]) * kOut);
         MUSTAFAR_PTRACE_END(7);
         return;
     }
@@ -2570,7 +2606,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     float* s_m = red + kWaves * G * 64;                          // [2 pairs][G]
     float* s_l = s_m + 2 * G;                                    // [2 pairs][G]
     __syncthreads();   // every wave is done with its stage window
-    if (lane < 2) s_m[pair * G + h0 + lane] = lane ? m_run[1] : m_run[0];   // (each wave: the maxima of its two heads)
+    if (has_heads && lane < HW) s_m[pair * G + h0 + lane] = lane ? m_run[HW - 1] : m_run[0];   // (each wave: the maxima of its heads)
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < G; h++) {
@@ -2578,7 +2614,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
         const float M = fmaxf(s_m[h], s_m[G + h]);
         // a pair without blocks weighs nothing; the e scale leaves here (a power of two: exact)
         const float scale = (mw == -INFINITY) ? 0.f : __expf(mw - M) * (ENG == 2 ? 0x1p-15f : 1.f);
-        if (lane == 0 && (h >> 1) == (int)odd) s_l[pair * G + h] = l_run[h & 1] * scale;   // (the wave that finished head h)
+        if (lane == 0 && has_heads && h / HW == (G >= 2 ? (int)odd : 0)) s_l[pair * G + h] = l_run[h % HW] * scale;   // (the wave that finished head h)
         red[(wave * G + h) * 64 + lane] = acc[h] * scale;
     }
     __syncthreads();
@@ -2954,7 +2990,10 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
     // (round 3, tokens/s one-pass vs two launches -- dot2: c3 5110 vs 4180, c4 1540 vs 1350, c5 3470 vs 3130; fma_mix: c4 1416 vs
     // 1353, c5 3111 vs 3131); the round-2 pair form (G < 4) while kv-heads x T is small (c2: 1650 vs 1310)
     // (the matrix-pipe engine has the pair form only: lean == 1 keeps its round-2 whole-block kernel, as lean == 0 does)
-    const bool lean_form = G == 4 && onepass_lean() != 0 && !(fma_engine() == 1 && onepass_lean() == 1);
+    // (G < 4 -- MHA, GQA-2 -- has the pair form only, on the v_fma_mix engine: round 4; before, its fused calls ran round 2's
+    // decode_onepass_kernel, which reads neither extents nor a device-side T)
+    const bool lean_form = G == 4 ? onepass_lean() != 0 && !(fma_engine() == 1 && onepass_lean() == 1) : onepass_lean() == 2;
+    const int eng = G == 4 ? fma_engine() : 0;
     const bool small = (int64_t)(Batch_Size / groups) * T <= 768000;
     // appended extents are read by the pair form of the one-pass launch only
     if (extents && !(T > 0 && lean_form && onepass_lean() == 2 && onepass_enabled(Batch_Size / groups, T) && (ld_scores & 31) == 0))
@@ -3010,15 +3049,21 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                           vc.bmp, vz, vc.idx, vc.nz_offset, a, kc.bmp_head_stride, kc.idx_head_stride, (uint32_t)kc.nz_head_stride,    \
                           vc.bmp_head_stride, vc.idx_head_stride, (uint32_t)vc.nz_head_stride)
             if (lp) {
-                if (extents) {
-                    if (fma_engine() == 2)      MUSTAFAR_LL((decode_onepass_leanpair_kernel<2, true>));
-                    else if (fma_engine() == 1) MUSTAFAR_LL((decode_onepass_leanpair_kernel<1, true>));
-                    else                        MUSTAFAR_LL((decode_onepass_leanpair_kernel<0, true>));
-                } else {
-                    if (fma_engine() == 2)      MUSTAFAR_LL((decode_onepass_leanpair_kernel<2>));
-                    else if (fma_engine() == 1) MUSTAFAR_LL((decode_onepass_leanpair_kernel<1>));
-                    else                        MUSTAFAR_LL((decode_onepass_leanpair_kernel<0>));
-                }
+#define MUSTAFAR_LP(EXTV)                                                                                   \
+    do {                                                                                                    \
+        if (G == 2)        MUSTAFAR_LL((decode_onepass_leanpair_kernel<0, EXTV, 2>));                       \
+        else if (G == 1)   MUSTAFAR_LL((decode_onepass_leanpair_kernel<0, EXTV, 1>));                       \
+        else if (eng == 2) MUSTAFAR_LL((decode_onepass_leanpair_kernel<2, EXTV>));                          \
+        else if (eng == 1) MUSTAFAR_LL((decode_onepass_leanpair_kernel<1, EXTV>));                          \
+        else               MUSTAFAR_LL((decode_onepass_leanpair_kernel<0, EXTV>));                          \
+    } while (0)
+                // (G = 1 without extents: the plain instantiation comes out of the register allocator with a 68-byte private segment it
+                // never touches, and a kernel with a private segment is launched with scratch (+1 % measured on the GQA-4 form); the
+                // extents instantiation has none and serves the same launch with every block in the base views)
+                if (!extents && G == 1) a.nb0 = ntb;
+                if (extents || G == 1) MUSTAFAR_LP(true);
+                else                   MUSTAFAR_LP(false);
+#undef MUSTAFAR_LP
             } else {
                 if (fma_engine() == 2) MUSTAFAR_LL((decode_onepass_lean_kernel<2>));
                 else                   MUSTAFAR_LL((decode_onepass_lean_kernel<0>));
@@ -3026,7 +3071,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
 #undef MUSTAFAR_LL
             if (prof) { g_prof.onepass++; g_prof.n++; }
             onepass_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
-            t_last_choice = fma_engine() | (1 << 4) | ((lp ? 2 : 1) << 8);
+            t_last_choice = eng | (1 << 4) | ((lp ? 2 : 1) << 8);
             return (int)hipGetLastError();
         }
         const bool pair = fma_engine() != 1 || G != 4;                      // two waves per block unless the matrix-pipe engine runs
@@ -3186,7 +3231,11 @@ int mustafar_decode_reads_extents(int num_key_value_groups, int ld_scores, uint3
     const uint32_t f_eng = flags & 7u, f_str = (flags >> 4) & 3u;
     if (f_eng > 3u || f_str > 2u || (flags & ~0x37u)) return 0;
     if (f_str == 1u || (f_str == 0u && onepass_mode() == 0)) return 0;   // two launches asked for (by the call or by the process default)
-    return pick_g(num_key_value_groups) == 4 && onepass_lean() == 2 && (ld_scores & 31) == 0 && g_onepass_wgs <= 0 &&
+    (void)onepass_target_wgs(true);   // (reads MUSTAFAR_ONEPASS_WGS: the shape rule below depends on it)
+    // rows so long that four blocks per workgroup leave more slabs than the row kernel folds (T > ~127 k tokens; ld_scores >= T
+    // stands in for T): decode_attention then gives a workgroup more blocks, which may straddle extents -> not served
+    if (((ld_scores / 64 + 3) / 4) + kMaxWindow / kOneWinChunk > kMaxSlabs) return 0;
+    return num_key_value_groups >= 1 && onepass_lean() == 2 && (ld_scores & 31) == 0 && g_onepass_wgs <= 0 &&
            (onepass_lean_tbw() == 0 || onepass_lean_tbw() == 1 || onepass_lean_tbw() == 2);
 }
 

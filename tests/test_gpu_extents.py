@@ -48,10 +48,12 @@ def _run(attn, K0, V0, qs, ks, vs):
     return outs, past
 
 
-@pytest.mark.parametrize("engine", ["dot2", "valu", "mfma"])
-def test_extents_equal_in_place_append_and_dense_through_three_triggers(engine):
+# (hq, hkv): GQA-4 on the three engines; MHA (G = 1) and GQA-2 (G = 2) on the v_fma_mix engine their pair form runs (round 4: before,
+# only group counts % 4 == 0 could read extents)
+@pytest.mark.parametrize("engine,hq,hkv", [("dot2", 8, 2), ("valu", 8, 2), ("mfma", 8, 2), (None, 8, 8), (None, 8, 4)])
+def test_extents_equal_in_place_append_and_dense_through_three_triggers(engine, hq, hkv):
     torch.manual_seed(5)
-    bsz, hq, hkv, D = 2, 8, 2, 128
+    bsz, D = 2, 128
     L0, steps = 512 + R + 200, 56 + 2 * 256 + 9               # first trigger after 56 steps, then two more
     K0, V0 = (torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(2))
     qs = [torch.randn(bsz, hq, 1, D, device=DEV).half() for _ in range(steps)]
@@ -162,14 +164,15 @@ def test_engine_switch_to_a_form_without_extents_consolidates():
     assert not past[0].extents and past[0].tokens == past[4] == 512
 
 
-def test_one_graph_serves_the_cache_through_two_triggers_with_device_side_T():
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 8), (8, 4)])
+def test_one_graph_serves_the_cache_through_two_triggers_with_device_side_T(hq, hkv):
     """`t_device` / `t_capacity`: the launch is sized for a capacity and reads the compressed tokens in use from device memory.  ONE
     captured graph of the step is replayed across two 256-token triggers (run eagerly between replays: an extent each, 256 added
-    to the device T, 256 taken off the window counter); every checked step equals dense attention."""
+    to the device T, 256 taken off the window counter); every checked step equals dense attention.  GQA-4, MHA and GQA-2."""
     from mustafar_amd import _lib
     lib = _lib.load()
     torch.manual_seed(9)
-    bsz, hq, hkv, D = 2, 8, 2, 128
+    bsz, D = 2, 128
     L0 = 512 + R + 250                                         # first trigger at the 6th decode step, the second 256 steps later
     K0, V0 = (torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(2))
     attn = _attn(hq, hkv)
