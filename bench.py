@@ -53,6 +53,8 @@ CONFIGS = {  # name: (label, Hq, Hkv, sparsity, L, batch)
     "s16": ("Llama-3-8B 70% L=16384 b8", 32, 8, 0.7, 16384, 8),
     "s32": ("Llama-3-8B 70% L=32768 b8", 32, 8, 0.7, 32768, 8),
 }
+CONFIGS["t8192"] = ("Llama-3-8B 70% T=8192 b8 [tools only]", 32, 8, 0.7, 8192 + 32, 8)
+CONFIGS["t8448"] = ("Llama-3-8B 70% T=8448 b8 [tools only]", 32, 8, 0.7, 8448 + 32, 8)
 CONFIGS["m8"] = ("Llama-2-7B (MHA) 70% L=8192 b8 [tools only]", 32, 32, 0.7, 8192, 8)
 CONFIGS["g2"] = ("GQA-2 (32 q / 16 kv heads) 70% L=8192 b8 [tools only]", 32, 16, 0.7, 8192, 8)
 SEQ_SWEEP = ("s4", "c3", "s16", "s32")
@@ -305,6 +307,23 @@ class Workload:
         same = all(torch.equal(a, b) for a, b in zip(got, want))
         return dt, same
 
+    def rehearse_trigger(self):
+        """One untimed batched trigger of all layers on throwaway window copies (the extents are dropped again): the first 32-layer
+        trigger of a process pays a one-off ~5 ms inside the driver (tools/bench_extent_append.py), which is not a property of the step."""
+        from mustafar_amd.cache import CompressedArena
+        from mustafar_amd import compression
+        state = self.fused_state()
+        if not all(isinstance(p[0], CompressedArena) and p[1].len >= 256 for p in state):
+            return
+        kth_k, kth_v = compression.kth_from_sparsity(self.cfg.k_sparsity, D), compression.kth_from_sparsity(self.cfg.v_sparsity, D)
+        pairs = [(p[0], p[2]) for p in state]
+        CompressedArena.append_extent_pairs(pairs, [(p[1].buf.clone(), p[3].buf.clone()) for p in state], kth_k, kth_v, state[0][1].len,
+                                            CompressedArena.prepare_extents(pairs, kth_k, kth_v))
+        torch.cuda.synchronize(self.dev)
+        for a, b in pairs:
+            a.drop_extents()
+            b.drop_extents()
+
     def timed_graph(self, steps, warmup, start_at_trigger_distance=None, device_t=False):
         """The fused call sequence of a whole step (all layers) captured ONCE into a hipGraph and replayed per step;
         a device-side counter grows the windows between replays.  A step that fires the 256-token compression
@@ -352,6 +371,10 @@ class Workload:
             p = state[0]
             return 256 - ((p[5] + box["since"] - R - p[4]) % 256)
 
+        def copy_window(w):   # (a shallow copy: prepare_triggers only looks at lengths and capacities)
+            import copy
+            return copy.copy(w)
+
         def capture_ahead():
             """The graph of the steps BEHIND the coming trigger (256 more compressed tokens, windows back at R rows), recorded while
             the current graph is still being replayed -- the host has nothing else to do between replays -- so the trigger step
@@ -366,18 +389,23 @@ class Workload:
 
         def step():
             if until_trigger() == 1:
+                # the trigger step (model :324-398).  Round 4: its decode comes from the graph like every other step (the windows
+                # reach R + 256 rows), then ALL layers' prune + compress + extent append run from two library calls with one host
+                # read between them, into storage prepared 8 steps ahead (hook.py: run_triggers / prepare_triggers; no allocation here)
                 torch.cuda.synchronize(dev)      # (the syncs bracket the trigger step for `trigger_step_ms`; they cost the leg < 0.1 %)
                 t0 = time.perf_counter()
+                box["g"].replay()
+                box["since"] += 1
                 for l in range(layers):
                     state[l] = attn.advance(state[l], box["since"])
-                self.one_step(state)             # eager: prune + compress + append inside decode_fused
+                state[:] = attn.run_triggers(state, box.pop("pool", None))
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
                 box["triggers"] += 1
                 ahead = box["next"]
-                if one_graph:          # the same graph goes on: 256 more tokens in use, the windows slid by 256 (the eager step appended one row)
+                if one_graph:          # the same graph goes on: 256 more tokens in use, the windows slid by 256
                     t_dev.add_(256)
-                    counter.add_(1 - 256)
+                    counter.add_(-256)
                     box["since"] = 0
                     box["base"] = box.get("base", 0) + 1
                 elif ahead is not None and ahead[1] == signature(state):
@@ -390,8 +418,12 @@ class Workload:
                                                                      "same graph (device-side T)" if one_graph else
                                                                      "graph recorded ahead" if ahead is not None and box["g"] is ahead[0] else "re-captured"))
             else:
-                if box["next"] is None and until_trigger() == 8 and not self.no_capture_ahead and not one_graph:
-                    capture_ahead()
+                if until_trigger() == 8:
+                    if box["next"] is None and not self.no_capture_ahead and not one_graph:
+                        capture_ahead()
+                    if "pool" not in box:
+                        fut = [attn.advance((p[0], copy_window(p[1]), p[2], copy_window(p[3]), p[4], p[5]), box["since"]) for p in state]
+                        box["pool"] = attn.prepare_triggers(fut)
                 box["g"].replay()
                 box["since"] += 1
 
@@ -414,6 +446,14 @@ class Workload:
         nprof = min(steps, 10)
         kern = self.profile(lambda: [self.one_step(state) for _ in range(nprof)], nprof * layers)
         self.extra["triggers_in_timed_region"] = box["triggers"]
+        if box["triggers"] and hasattr(state[0][0], "consolidate") and state[0][0].extents:
+            # what a full extent table (64 triggers) costs: every layer's base + extents re-housed into one base (a copy of the cache)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            merged = [(p[0].consolidate(), p[2].consolidate()) for p in state]
+            torch.cuda.synchronize(dev)
+            self.extra["consolidate_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+            del merged
         del state
         return dt, kern
 
@@ -620,12 +660,15 @@ def main():
     if use_graph and not a.no_trigger_leg:
         nst = 256
         w.extra.pop("trigger_step_ms", None)
+        w.rehearse_trigger()
         dt_t, _ = w.timed_graph(nst, 1)
         trig = {"value": round(world * w.batch * nst / dt_t, 2), "unit": "tokens/s", "steps": nst, "ms_per_step": round(dt_t / nst * 1e3, 4),
                 "triggers": w.extra.get("triggers_in_timed_region"),
                 "trigger_step_ms": w.extra.get("trigger_step_ms"),
-                "trigger_step_ms_note": "(eager decode step + prune/compress/append of 256 tokens per head and layer, switch to the graph of the longer cache), wall ms each; a replayed step is ms_per_step",
-                "note": "the trigger step runs eagerly (prune + compress of 256 tokens per head and layer into an extent of the cache); the graph of the steps behind it is recorded 8 steps ahead, between replays"}
+                "consolidate_ms": w.extra.get("consolidate_ms"),
+                "consolidate_ms_note": "all 32 layers' K and V caches (base + the extent of this leg) re-housed into one base each: what a full extent table costs once per 64 triggers",
+                "trigger_step_ms_note": "(the step's decode replayed from the graph + prune/compress of 256 tokens per head into an extent for ALL layers from two library calls and one host read, switch to the graph of the longer cache), wall ms each; a replayed step is ms_per_step",
+                "note": "the trigger step: decode from the graph, then every layer's 256 oldest window tokens pruned + compressed into an extent of its cache (storage prepared 8 steps ahead: no allocation in the step); the graph of the steps behind it is recorded 8 steps ahead, between replays"}
         w.extra.pop("trigger_step_ms", None)
         dt_1, _ = w.timed_graph(nst, 1, device_t=True)
         trig["one_graph_device_side_T"] = {"value": round(world * w.batch * nst / dt_1, 2), "unit": "tokens/s", "ms_per_step": round(dt_1 / nst * 1e3, 4),

@@ -242,6 +242,34 @@ int mustafar_cache_rehouse(void* stream, const mustafar_cache_view* src, const m
 int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int64_t head_stride, int Bp, int len, int drop);
 
 /*
+ * The 256-token trigger of ALL layers in two calls (round 4).  The reference runs the trigger layer by layer inside the attention
+ * forward (models/llama_mustafar_kernel.py:324-398), each with a dozen host reads; here the layers' window rows are pruned and
+ * compressed into one EXTENT each (mustafar_decode_attention_extents) by launches issued back to back from ONE call, the caller reads
+ * every layer's flag and lengths with ONE copy, and a second call lists the extents in the device tables and slides the windows.
+ * `items`: HOST array, one entry per layer.
+ *   k_window / v_window   [B', capacity, 128] window buffers; rows [0, t) of every head are the raw tokens to compress
+ *   k_dst / v_dst         views of the layer's new, EMPTY extent (nz_offset written, idx[h][0] == 0; nz_head_stride != 0)
+ *   k_table_slot / v_table_slot   device addresses the views are written to by the finish call (the entry of the layer's extent
+ *                         tables that the next decode launch will read), or NULL
+ *   k_head_total / v_head_total / overflow_flag   as mustafar_cache_append_kv (the flags zeroed by the caller; one per layer)
+ * mustafar_trigger_compress_batch: `scratch` = n x mustafar_compress_scratch_bytes(B', t) bytes; region_halfs as mustafar_cache_append_kv.
+ * mustafar_trigger_finish_batch: `len` rows of every window are valid, `drop` (= t) leave; at most 64 rows stay.
+ */
+typedef struct mustafar_trigger_item {
+    void* k_window;
+    void* v_window;
+    mustafar_cache_view  k_dst, v_dst;
+    mustafar_cache_view* k_table_slot;
+    mustafar_cache_view* v_table_slot;
+    int64_t* k_head_total;
+    int64_t* v_head_total;
+    int32_t* overflow_flag;
+} mustafar_trigger_item;
+int mustafar_trigger_compress_batch(void* stream, int n, const mustafar_trigger_item* items, int64_t head_stride, int Bp, int t, int D,
+                                    int kth_k, int kth_v, int64_t k_region_halfs, int64_t v_region_halfs, void* scratch);
+int mustafar_trigger_finish_batch(void* stream, int n, const mustafar_trigger_item* items, int64_t head_stride, int Bp, int len, int drop);
+
+/*
  * FMA engine, process default (a fused call may carry its own in `flags`):
  *   2 = v_dot2_f32_f16 on pairs of tiles (default; GQA-4 one-pass decode launches).  One instruction does two tiles of one head, so
  *       the FMA phase costs 2 + 1.5 cheap instead of 4 vector instructions per tile.  For normal fp16 inputs the instruction is a

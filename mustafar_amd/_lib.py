@@ -22,6 +22,15 @@ class CacheView(ctypes.Structure):
 
 _view_p = ctypes.POINTER(CacheView)
 
+
+class TriggerItem(ctypes.Structure):
+    """`mustafar_trigger_item` of include/mustafar_hip.h: one layer of a batched 256-token trigger."""
+    _fields_ = [("k_window", _vp), ("v_window", _vp), ("k_dst", CacheView), ("v_dst", CacheView), ("k_table_slot", _vp), ("v_table_slot", _vp),
+                ("k_head_total", _vp), ("v_head_total", _vp), ("overflow_flag", _vp)]
+
+
+_item_p = ctypes.POINTER(TriggerItem)
+
 # name -> (restype, argtypes); must list every symbol of include/mustafar_hip.h
 SIGNATURES = {
     "mustafar_abi_version": (_i32, []),
@@ -45,6 +54,8 @@ SIGNATURES = {
     "mustafar_compress_scratch_bytes": (_i64, [_i32, _i32]),
     "mustafar_cache_append_kv": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _view_p, _view_p, _i32, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mustafar_window_drop_front": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32]),
+    "mustafar_trigger_compress_batch": (_i32, [_vp, _i32, _item_p, _i64, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp]),
+    "mustafar_trigger_finish_batch": (_i32, [_vp, _i32, _item_p, _i64, _i32, _i32, _i32]),
     "mustafar_cache_rehouse": (_i32, [_vp, _view_p, _view_p, _i32, _i32, _i64]),
     "mustafar_decode_workspace_bytes": (_i64, [_i32] * 4),
     "mustafar_set_fma_engine": (_i32, [_i32]),

@@ -48,6 +48,44 @@ from . import _lib
 DEFAULT_SLACK = 0.03
 
 
+class ExtentPool:
+    """ONE allocation holding the extents of one trigger of every layer (2 per layer: K, V -- all of one geometry: 256 tokens, the
+    largest region any layer expects), their status words ([flag, K lengths, V lengths] per layer) and the compression scratch;
+    initialised by three launches.  The extents are `CompressedArena`s carved from it (they keep the allocation alive)."""
+
+    def __init__(self, n_layers: int, heads: int, device, nz_cap: int):
+        self.n, self.heads, self.device, self.nz_cap, self.used = n_layers, heads, device, nz_cap, False
+        offs, ext_bytes = CompressedArena._layout(heads, 256, nz_cap)
+        self.ext_bytes, self._offs = ext_bytes, offs
+        ne = 2 * n_layers
+        self.status_words = 1 + 2 * heads                                  # int64 per layer: flag (low 4 bytes), K totals, V totals
+        status_bytes = _round_up(n_layers * self.status_words * 8, 256)
+        scratch_bytes = _round_up(n_layers * int(_lib.load().mustafar_compress_scratch_bytes(heads, 256)), 256)
+        self.buf = torch.empty(ne * ext_bytes + status_bytes + scratch_bytes, dtype=torch.uint8, device=device)
+        self.status = self.buf[ne * ext_bytes:ne * ext_bytes + n_layers * self.status_words * 8].view(torch.int64).view(n_layers, self.status_words)
+        self.scratch = self.buf[ne * ext_bytes + status_bytes:]
+        tiles = 256 * CompressedArena.TILES_PER_TOKEN
+        w = self.buf[:ne * ext_bytes].view(torch.int32).view(ne, ext_bytes // 4)
+        w[:, offs["nz_offset"] // 4:offs["nz_offset"] // 4 + heads] = _head_index(heads, device) * (nz_cap // 8)      # stream starts of the heads
+        torch.as_strided(w, (ne, heads), (ext_bytes // 4, tiles + 1), offs["idx"] // 4).zero_()                         # offset 0 of every head
+        self.status.zero_()                                                                                              # flags (and lengths)
+        self._host = torch.empty((n_layers, self.status_words), dtype=torch.int64).pin_memory()                         # landing area of read_status()
+
+    def extent(self, j: int, which: str, slack: float) -> "CompressedArena":
+        return CompressedArena(self.heads, which, self.device, 256, self.nz_cap, slack, storage=self.buf[j * self.ext_bytes:(j + 1) * self.ext_bytes])
+
+    def totals_ptr(self, j: int) -> int:       # extent j = 2 * layer + side
+        return self.status.data_ptr() + ((j // 2) * self.status_words + 1 + (j % 2) * self.heads) * 8
+
+    def flag_ptr(self, layer: int) -> int:
+        return self.status.data_ptr() + layer * self.status_words * 8
+
+    def read_status(self) -> torch.Tensor:
+        self._host.copy_(self.status, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._host
+
+
 class ArenaAppendTimeout(RuntimeError):
     """The one-pass compression launch gave up waiting for a predecessor block's length (device flag bit 1).  The appended
     tokens are incomplete; MUSTAFAR_COMPRESS=twopass selects the form without that dependence."""
@@ -82,29 +120,42 @@ class CompressedArena:
     MAX_EXTENTS = 64      # appended 256-token extents listed in the device table (16 k tokens of generation) before a consolidation
     VIEW_BYTES = ctypes.sizeof(_lib.CacheView)
 
-    def __init__(self, heads: int, which: str, device, cap_tokens: int, nz_cap: int, slack: float = DEFAULT_SLACK):
+    def __init__(self, heads: int, which: str, device, cap_tokens: int, nz_cap: int, slack: float = DEFAULT_SLACK,
+                 storage: Optional[torch.Tensor] = None):
+        """storage: a uint8 tensor of `_layout(...)[1]` bytes to carve the arena from (an extent of a pooled trigger: the caller
+        has initialised it -- nz_offset, idx[:, 0], flag -- for all its extents at once); None: an allocation of its own."""
         assert which in ("key", "value") and cap_tokens % 64 == 0 and nz_cap % 8 == 0
         self.heads, self.which, self.device, self.slack = heads, which, device, slack
         self.tokens = 0
         self.extents: List["CompressedArena"] = []   # appended 256-token extents, oldest first (module docstring)
         self._ext_table = None                        # device copy of their views (MAX_EXTENTS x mustafar_cache_view)
-        self._alloc(cap_tokens, nz_cap)
-        self._init_empty()
+        self._alloc(cap_tokens, nz_cap, storage)
+        if storage is None:
+            self._init_empty()
 
     # ---- storage ---------------------------------------------------------------------------------------------
-    def _alloc(self, cap_tokens: int, nz_cap: int):
+    @classmethod
+    def _layout(cls, heads: int, cap_tokens: int, nz_cap: int):
+        """Byte offsets of the arrays inside an arena's one allocation, and its size."""
+        tiles = cap_tokens * cls.TILES_PER_TOKEN
+        sizes = (("bmp", heads * tiles * 8), ("nz", heads * nz_cap * 2), ("idx", heads * (tiles + 1) * 4), ("nz_offset", heads * 4),
+                 ("totals", heads * 8), ("flag", 4))
+        offs, total = {}, 0
+        for name, n in sizes:
+            offs[name] = total
+            total = _round_up(total + n, 256)
+        return offs, total
+
+    def _alloc(self, cap_tokens: int, nz_cap: int, storage: Optional[torch.Tensor] = None):
         """ONE device allocation per arena, carved into the four arrays of the format (+ the per-head lengths and the flag the
         append launch writes): a re-housing is one allocation and one copy launch (mustafar_cache_rehouse)."""
         tiles = cap_tokens * self.TILES_PER_TOKEN
         self.cap_tokens, self.nz_cap = cap_tokens, nz_cap
         H = self.heads
-        sizes = (("bmp", H * tiles * 8), ("nz", H * nz_cap * 2), ("idx", H * (tiles + 1) * 4), ("nz_offset", H * 4), ("totals", H * 8),
-                 ("flag", 4))
-        offs, total = {}, 0
-        for name, n in sizes:
-            offs[name] = total
-            total = _round_up(total + n, 256)
-        self._buf = buf = torch.empty(total, dtype=torch.uint8, device=self.device)
+        offs, total = self._layout(H, cap_tokens, nz_cap)
+        if storage is not None:
+            assert storage.dtype == torch.uint8 and storage.numel() == total and storage.is_contiguous()
+        self._buf = buf = storage if storage is not None else torch.empty(total, dtype=torch.uint8, device=self.device)
         cut = lambda name, n, dt: buf[offs[name]:offs[name] + n].view(dt)
         self.bmp = cut("bmp", H * tiles * 8, torch.int64).view(H, tiles)
         self.idx = cut("idx", H * (tiles + 1) * 4, torch.int32).view(H, tiles + 1)
@@ -116,7 +167,6 @@ class CompressedArena:
         self._host_totals = None                           # pinned landing area of an asynchronous append's lengths
         self._pending = None                               # (event, tokens appended) behind an asynchronous append
         self._host_flag = None
-        self._fresh = True                                 # nz_offset / idx[:, 0] / flag not yet written (done by the first use)
         self._view = _lib.CacheView(self.bmp.data_ptr(), self.nz.data_ptr(), self.idx.data_ptr(), self.nz_offset.data_ptr(),
                                     tiles, tiles + 1,
                                     nz_cap // 8 if (H * (nz_cap // 8) < 2 ** 32 and os.environ.get("MUSTAFAR_NZ_STRIDE", "1") != "0") else 0)
@@ -126,7 +176,6 @@ class CompressedArena:
         torch.mul(_head_index(self.heads, self.device), self.nz_cap // 8, out=self.nz_offset)
         self.idx[:, 0] = 0
         self._overflow.zero_()
-        self._fresh = False
 
     @property
     def view(self) -> "_lib.CacheView":
@@ -146,7 +195,8 @@ class CompressedArena:
         flag = int(self._host_flag[0])
         if flag:
             self.tokens -= t                     # the append did not complete: the cache is what it was before it
-            self._overflow.zero_()
+            if self.which == "key":              # (the pair's flag lives in the K arena)
+                self._overflow.zero_()
             if flag & 2:
                 raise ArenaAppendTimeout("CompressedArena: a block of the one-pass compression timed out waiting for the stream lengths in front "
                                          "of it; the 256 tokens of this trigger were not appended (MUSTAFAR_COMPRESS=twopass avoids the wait)")
@@ -166,6 +216,8 @@ class CompressedArena:
 
     def poll(self) -> None:
         self._settle(wait=False)
+        for e in self.extents:                   # (an extent that took the asynchronous path reports through the same mechanism)
+            e._settle(wait=False)
 
     def view_ptr(self):
         return ctypes.byref(self._view)
@@ -219,6 +271,89 @@ class CompressedArena:
         k_arena._list_extent(ek)
         v_arena._list_extent(ev)
 
+    # ---- the trigger of ALL layers at once (round 4) ------------------------------------------------------------------------------
+    @staticmethod
+    def prepare_extents(pairs, kth_k: int, kth_v: int) -> "ExtentPool":
+        """Storage for the NEXT trigger of every layer, allocated and initialised ahead of it (the host has nothing else to do between
+        graph replays): ONE allocation for the 2 x len(pairs) extents, their status words and the compression scratch; three small
+        launches set every extent's stream starts, first offsets and flags.  `pairs`: [(k_arena, v_arena), ...], one per layer."""
+        k0 = pairs[0][0]
+        heads, dev = k0.heads, k0.device
+        need = 0
+        for ka, va in pairs:
+            if ka.heads != heads or va.heads != heads:
+                raise RuntimeError("prepare_extents: every layer must have the same number of kv-heads")
+            need = max(need, ka._expected_append(256, kth_k), va._expected_append(256, kth_v))
+        return ExtentPool(len(pairs), heads, dev, _cap_nz(need, 0.0))
+
+    @staticmethod
+    def append_extent_pairs(pairs, rows, kth_k: int, kth_v: int, window_len: int, pool: Optional["ExtentPool"] = None) -> None:
+        """The 256-token trigger of every layer (model :324-398 runs it layer by layer inside the attention forward): rows [0, 256) of
+        each layer's window buffers become an extent of its K and of its V arena, and both windows slide by 256 rows.
+            pairs : [(k_arena, v_arena), ...]      rows : [(k_buf, v_buf), ...] the window buffers [B, Hkv, cap, 128], `window_len` rows valid
+        The layers' compression launches are issued back to back by ONE library call into a pooled allocation, ONE copy + wait brings
+        every layer's flag and lengths to the host, one more call lists the extents in the device tables and slides the windows
+        (a launch per layer).  A layer whose head outgrew its region (rows full of ties) is redone on its own at the measured size --
+        its raw rows are still in place: nothing slides before every flag has been seen."""
+        n = len(pairs)
+        if n == 0:
+            return
+        k0 = pairs[0][0]
+        for (ka, va), (kr, vr) in zip(pairs, rows):
+            if len(ka.extents) >= ka.MAX_EXTENTS or len(ka.extents) != len(va.extents) or ka.tokens % 256 or ka.tokens != va.tokens:
+                raise RuntimeError("append_extent_pairs: extent table full (consolidate() first) or K / V out of step")
+            if kr.shape != vr.shape or kr.dtype != torch.float16 or kr.dim() != 4 or kr.shape[0] * kr.shape[1] != ka.heads or kr.shape[3] != 128 \
+                    or kr.shape[2] < window_len or window_len < 256 or not kr.is_contiguous() or not vr.is_contiguous() or kr.shape != rows[0][0].shape:
+                raise RuntimeError("append_extent_pairs expects contiguous fp16 [B, Hkv, rows >= window_len >= 256, 128] buffers of one shape")
+        if pool is None or pool.n != n or pool.heads != k0.heads or pool.used:
+            pool = CompressedArena.prepare_extents(pairs, kth_k, kth_v)
+        pool.used = True
+        L = _lib.load()
+        dev = k0.device
+        items = (_lib.TriggerItem * n)()
+        made = []
+        for i, ((ka, va), (kr, vr)) in enumerate(zip(pairs, rows)):
+            ek, ev = pool.extent(2 * i, "key", ka.slack), pool.extent(2 * i + 1, "value", va.slack)
+            ka.ext_table, va.ext_table
+            it = items[i]
+            it.k_window, it.v_window = kr.data_ptr(), vr.data_ptr()
+            it.k_dst, it.v_dst = ek._view, ev._view
+            it.k_table_slot = ka._ext_table.data_ptr() + len(ka.extents) * CompressedArena.VIEW_BYTES
+            it.v_table_slot = va._ext_table.data_ptr() + len(va.extents) * CompressedArena.VIEW_BYTES
+            it.k_head_total, it.v_head_total, it.overflow_flag = pool.totals_ptr(2 * i), pool.totals_ptr(2 * i + 1), pool.flag_ptr(i)
+            made.append((ek, ev))
+        head_stride = rows[0][0].shape[2] * 128
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(L.mustafar_trigger_compress_batch(st, n, items, head_stride, k0.heads, 256, 128, kth_k, kth_v, pool.nz_cap, pool.nz_cap,
+                                                         pool.scratch.data_ptr()), "mustafar_trigger_compress_batch")
+            host = pool.read_status()                 # ONE copy into pinned memory + ONE wait: [n pairs][flag, K totals, V totals]
+            redo = []
+            for i in range(n):
+                flag = int(host[i, 0]) & 0xffffffff
+                if flag & 2:
+                    raise ArenaAppendTimeout("CompressedArena: a block of the one-pass compression timed out waiting for the stream lengths in "
+                                             "front of it; nothing was appended (MUSTAFAR_COMPRESS=twopass avoids the wait)")
+                if flag:
+                    redo.append(i)
+            keep = [i for i in range(n) if i not in redo]
+            if keep:
+                sub = items if not redo else (_lib.TriggerItem * len(keep))(*[items[i] for i in keep])
+                _lib.check(L.mustafar_trigger_finish_batch(st, len(keep), sub, head_stride, k0.heads, window_len, 256), "mustafar_trigger_finish_batch")
+        H = k0.heads
+        for i in keep:
+            (ka, va), (ek, ev) = pairs[i], made[i]
+            ek.used, ek.tokens = host[i, 1:1 + H].clone(), 256
+            ev.used, ev.tokens = host[i, 1 + H:1 + 2 * H].clone(), 256
+            ka.extents.append(ek)
+            va.extents.append(ev)
+        for i in redo:                                # bit 0: on its own, at the size the launch reported (append_window_pair's repeat)
+            (ka, va), (kr, vr) = pairs[i], rows[i]
+            CompressedArena.append_extent_pair(ka, va, kr, vr, kth_k, kth_v)
+            with torch.cuda.device(dev):
+                _lib.check(L.mustafar_window_drop_front(torch.cuda.current_stream(dev).cuda_stream, kr.data_ptr(), vr.data_ptr(), head_stride,
+                                                        H, window_len, 256), "mustafar_window_drop_front")
+
     def drop_extents(self) -> None:
         """Back to the base tokens (the extents never touched them); their table entries are overwritten by the next ones."""
         self.extents = []
@@ -243,7 +378,6 @@ class CompressedArena:
                                                          ctypes.byref(self._view), self.heads, tokens, _round_up(m, 8))
             _lib.check(err, "mustafar_cache_rehouse")
             self._overflow.zero_()
-            self._fresh = False
         else:   # (MUSTAFAR_NZ_STRIDE=0, an experiment switch: the views carry no stream stride; tensor copies instead)
             self._init_empty()
             t2 = tokens * self.TILES_PER_TOKEN
@@ -339,7 +473,8 @@ class CompressedArena:
             a._make_room(t, used + (a._expected_append(t, kth) if expect else 0))
         worst = t * 128
         safe = all(a.nz_cap - (int(a.used.max()) if a.tokens else 0) >= worst for a in (k_arena, v_arena))
-        v_arena._overflow = k_arena._overflow                       # one flag per pair and call
+        # (one flag per pair and call: K's.  It is NOT stored in the V arena: a view of K's allocation there kept K's old buffer alive
+        # -- a whole extra K arena of memory -- from a re-housing of K until the next trigger)
         with torch.cuda.device(dev):
             if safe:   # nothing can overflow: stay asynchronous, lengths and flag through pinned memory (looked at on the next use)
                 CompressedArena._launch_pair(k_arena, v_arena, k_rows, v_rows, t, kth_k, kth_v)
@@ -349,7 +484,7 @@ class CompressedArena:
                         a._host_totals = torch.zeros(a.heads, dtype=torch.int64).pin_memory()
                         a._host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
                     a._host_totals.copy_(a._totals, non_blocking=True)
-                    a._host_flag.copy_(a._overflow, non_blocking=True)
+                    a._host_flag.copy_(k_arena._overflow, non_blocking=True)
                 ev.record(torch.cuda.current_stream(dev))
                 for a in (k_arena, v_arena):
                     a._pending = (ev, t)

@@ -581,6 +581,36 @@ __global__ __launch_bounds__(kThreads) void window_drop_front_kernel(uint16_t* k
     }
 }
 
+// The tail of a trigger that grew the cache by an extent (cache.py: append_extent_pairs): the window slide of both sides and, by
+// one workgroup, the extent's two views into their slots of the device tables -- one launch per layer, no host copy.
+__global__ __launch_bounds__(kThreads) void trigger_finish_kernel(uint16_t* k_win, uint16_t* v_win, int64_t head_stride, int len, int drop,
+                                                                  mustafar_cache_view k_view, mustafar_cache_view v_view,
+                                                                  mustafar_cache_view* k_slot, mustafar_cache_view* v_slot)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const mustafar_cache_view& view = blockIdx.y ? v_view : k_view;
+        mustafar_cache_view* slot = blockIdx.y ? v_slot : k_slot;
+        if (slot) *slot = view;
+    }
+    if (drop <= 0 || len <= drop) return;
+    uint16_t* win = (blockIdx.y ? v_win : k_win) + blockIdx.x * head_stride;
+    const int n16 = (len - drop) * (kD / 8);   // 16-byte pieces to move (<= 4 per thread: checked on the host)
+    const uint4* src = reinterpret_cast<const uint4*>(win + (int64_t)drop * kD);
+    uint4* dst = reinterpret_cast<uint4*>(win);
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = threadIdx.x + i * kThreads;
+        if (p < n16) v[i] = src[p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = threadIdx.x + i * kThreads;
+        if (p < n16) dst[p] = v[i];
+    }
+}
+
 // Re-housing of a cache (cache.py: an arena moved into larger rows / regions): the three arrays of every head in ONE launch.
 // grid: x = 16-KiB pieces of a head's largest array, y = head, z = array (0 bitmaps, 1 offsets, 2 stream); z = 0 also writes
 // the destination's nz_offset (equally spaced regions).
@@ -806,6 +836,70 @@ int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int
     const int err = launch_meta(st, s, 2, Bp, t, static_cast<int32_t*>(scratch), overflow_flag, false);
     if (err) return err;
     return launch_pack(st, s, 2, Bp, t, overflow_flag);
+}
+
+// The trigger of ALL layers of a model in two calls (round 4; cache.py: append_extent_pairs): `items` is a HOST array, one entry per
+// layer.  (1) compress: one memset of the whole scratch, then the layers' compression launches back to back -- no host work in
+// between, nothing read back: the caller reads every layer's flag and lengths with ONE copy behind the call.
+int mustafar_trigger_compress_batch(void* stream, int n, const mustafar_trigger_item* items, int64_t head_stride, int Bp, int t, int D,
+                                    int kth_k, int kth_v, int64_t k_region_halfs, int64_t v_region_halfs, void* scratch)
+{
+    if (n < 1 || !items || D != kD || Bp < 1 || t < 64 || (t & 63) || head_stride < (int64_t)t * kD || kth_k < 0 || kth_k > kD || kth_v < 0 ||
+        kth_v > kD || !scratch)
+        return MUSTAFAR_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ntb = t / 64;
+    const int64_t per_item = mustafar_compress_scratch_bytes(Bp, t);
+    for (int i = 0; i < n; i++) {   // every item is checked before anything is launched
+        Rows r;
+        const mustafar_trigger_item& it = items[i];
+        if (!it.k_window || !it.v_window || !it.k_head_total || !it.v_head_total || !it.overflow_flag || !view_rows(&it.k_dst, 0, t, r) ||
+            !view_rows(&it.v_dst, 0, t, r) || !it.k_dst.nz || !it.v_dst.nz)
+            return MUSTAFAR_EINVAL;
+    }
+    const bool one_pass = one_pass_compress();
+    if (one_pass) {
+        const int err = (int)hipMemsetAsync(scratch, 0, (size_t)(per_item * n), st);   // the length words of every layer: not yet valid
+        if (err) return err;
+    }
+    for (int i = 0; i < n; i++) {
+        const mustafar_trigger_item& it = items[i];
+        Rows kr, vr;
+        (void)view_rows(&it.k_dst, 0, t, kr);
+        (void)view_rows(&it.v_dst, 0, t, vr);
+        Side s[2] = {
+            {static_cast<const uint16_t*>(it.k_window), head_stride, reinterpret_cast<int64_t*>(it.k_dst.bmp), reinterpret_cast<int32_t*>(it.k_dst.idx),
+             nullptr, it.k_head_total, nullptr, it.k_dst.nz_offset, static_cast<uint16_t*>(it.k_dst.nz), kr, k_region_halfs, kth_k, 1},
+            {static_cast<const uint16_t*>(it.v_window), head_stride, reinterpret_cast<int64_t*>(it.v_dst.bmp), reinterpret_cast<int32_t*>(it.v_dst.idx),
+             nullptr, it.v_head_total, nullptr, it.v_dst.nz_offset, static_cast<uint16_t*>(it.v_dst.nz), vr, v_region_halfs, kth_v, 0}};
+        unsigned char* sc = static_cast<unsigned char*>(scratch) + per_item * i;
+        if (one_pass) {
+            compress_block_kernel<<<dim3(ntb, Bp, 2), 64, 0, st>>>(s[0], s[1], ntb, reinterpret_cast<uint64_t*>(sc), it.overflow_flag);
+        } else {
+            int err = launch_meta(st, s, 2, Bp, t, reinterpret_cast<int32_t*>(sc), it.overflow_flag, false);
+            if (!err) err = launch_pack(st, s, 2, Bp, t, it.overflow_flag);
+            if (err) return err;
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+// (2) finish: per layer ONE launch that lists the extent in the two device tables (k_table_slot / v_table_slot; NULL: not listed) and
+// slides both windows by `drop` rows (model :392-393).  Called once the caller has seen every flag clear.
+int mustafar_trigger_finish_batch(void* stream, int n, const mustafar_trigger_item* items, int64_t head_stride, int Bp, int len, int drop)
+{
+    if (n < 1 || !items || Bp < 1 || drop < 0 || len < drop || head_stride < (int64_t)len * kD ||
+        (int64_t)(len - drop) * (kD / 8) > 4 * kThreads)   // at most 64 rows stay (the hook keeps residual_length = 32)
+        return MUSTAFAR_EINVAL;
+    for (int i = 0; i < n; i++)
+        if (!items[i].k_window || !items[i].v_window) return MUSTAFAR_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < n; i++) {
+        const mustafar_trigger_item& it = items[i];
+        trigger_finish_kernel<<<dim3(Bp, 2), kThreads, 0, st>>>(static_cast<uint16_t*>(it.k_window), static_cast<uint16_t*>(it.v_window), head_stride,
+                                                                len, drop, it.k_dst, it.v_dst, it.k_table_slot, it.v_table_slot);
+    }
+    return (int)hipGetLastError();
 }
 
 int mustafar_cache_rehouse(void* stream, const mustafar_cache_view* src, const mustafar_cache_view* dst, int Bp, int tokens,

@@ -2850,7 +2850,7 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
 
 extern "C" {
 
-int mustafar_abi_version(void) { return 103; }
+int mustafar_abi_version(void) { return 104; }
 
 int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
                    const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,

@@ -303,7 +303,7 @@ class MustafarAttention:
 
     def decode_fused(self, query_states, key_states, value_states, past, step_counter: Optional[torch.Tensor] = None,
                      attention_mask: Optional[torch.Tensor] = None, t_device: Optional[torch.Tensor] = None,
-                     t_capacity: Optional[int] = None):
+                     t_capacity: Optional[int] = None, defer_trigger: bool = False):
         """Same contract as decode() with api="native"; windows are `Window` objects appended in place.
 
         `attention_mask` is the hook's additive mask [bsz, 1, 1, kv_seq_len] (model :293-301), applied inside the softmax
@@ -315,6 +315,10 @@ class MustafarAttention:
         captured graph of this call can be replayed for consecutive steps (advance it with mustafar_counter_add once
         per step); the host-side lengths/`kv_seq_len` of the returned `past` then describe the FIRST replay and the
         256-token trigger is the caller's business (see bench.py).
+
+        `defer_trigger`: a step that reaches the 256-token trigger (model :324) returns with its windows at R + 256 rows and the
+        compression NOT run; the caller runs it for all layers at once with `run_triggers()` before the next step (round 4: one
+        library call issues every layer's compression, one host read, no allocation when `prepare_triggers()` was called ahead).
 
         `t_device` (int32 device tensor) + `t_capacity` (graph replay only: `step_counter` is required with them): the compressed
         tokens IN USE as a device quantity and the capacity the launch is sized for (a cache that grows by extents only).  ONE captured graph of the call then serves every compressed
@@ -403,25 +407,15 @@ class MustafarAttention:
         if step_counter is not None:
             return out, (k_c, k_w, v_c, v_w, C, kv_seq_len - 1)   # lengths advance with the device counter
         k_w.len = v_w.len = w_len
+        if defer_trigger:
+            return out, (k_c, k_w, v_c, v_w, C, kv_seq_len)
         if (kv_seq_len - cfg.residual_length - C) % 256 == 0 and w_len >= 256:                          # :324
             kth_k = compression.kth_from_sparsity(cfg.k_sparsity, D)
             kth_v = compression.kth_from_sparsity(cfg.v_sparsity, D)
             if use_arena or (cfg.arena and C == 0):
-                # prune (:325-326) + compress + append (:328-390) of the raw window rows in one launch, no host read
-                if C == 0:
-                    k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, None, self._slack())
-                    if cfg.extents:
-                        k_c.ext_table, v_c.ext_table
-                elif cfg.extents and k_c.tokens % 256 == 0 and L.mustafar_decode_reads_extents(groups, ld, flags):
-                    if len(k_c.extents) >= k_c.MAX_EXTENTS:          # table full: one copy of the cache, then extents again
-                        k_c, v_c = k_c.consolidate(), v_c.consolidate()
-                        k_c.ext_table, v_c.ext_table
-                    CompressedArena.append_extent_pair(k_c, v_c, k_w.buf, v_w.buf, kth_k, kth_v)
-                else:
-                    if k_c.extents:
-                        k_c, v_c = k_c.consolidate(), v_c.consolidate()
-                    CompressedArena.append_window_pair(k_c, v_c, k_w.buf, v_w.buf, 256, kth_k, kth_v)
-                Window.drop_front_pair(k_w, v_w, 256)                                                   # :392-393, in place
+                # prune (:325-326) + compress + append (:328-390) of the raw window rows in one launch
+                k_c, k_w, v_c, v_w, C, _ = self._trigger_one(k_c, k_w, v_c, v_w, C, kv_seq_len, kth_k, kth_v)
+                return out, (k_c, k_w, v_c, v_w, C, kv_seq_len)
             else:
                 k_blk = self.dh_prune_key(k_w.buf[:, :, :256, :]).reshape(Bkv, -1, D)                   # :325
                 v_blk = self.dh_prune_value(v_w.buf[:, :, :256, :]).reshape(Bkv, -1, D)                 # :326
@@ -435,6 +429,80 @@ class MustafarAttention:
                 v_w.drop_front(256)
             C += 256
         return out, (k_c, k_w, v_c, v_w, C, kv_seq_len)
+
+    # ---- the 256-token trigger of all layers at once (round 4) ----------------------------------------------------------------------
+    def trigger_due(self, past) -> bool:
+        """The step that produced `past` (its kv_seq_len already counted) reached the trigger of model :324."""
+        k_c, k_w, v_c, v_w, C, L = past
+        return isinstance(k_w, Window) and (L - self.cfg.residual_length - C) % 256 == 0 and k_w.len >= 256
+
+    def _batched_ok(self, past) -> bool:
+        k_c, k_w, v_c, v_w, C, L = past
+        flags = _lib.ENGINE_FLAGS[self.cfg.engine] | _lib.STRUCTURE_FLAGS[self.cfg.structure]
+        ld = (C + 256 + k_w.cap + 31) // 32 * 32
+        return self.cfg.extents and isinstance(k_c, CompressedArena) and C > 0 and k_c.tokens % 256 == 0 and \
+            len(k_c.extents) < k_c.MAX_EXTENTS and bool(_lib.load().mustafar_decode_reads_extents(self.num_key_value_groups, ld, flags))
+
+    def prepare_triggers(self, pasts):
+        """Allocate and initialise the storage of the coming trigger of every layer ahead of it (one allocation, three launches):
+        run_triggers() then allocates nothing.  Returns the pool to hand to run_triggers (None where the batched form does not apply)."""
+        if not pasts or not all(self._batched_ok(p) for p in pasts):
+            return None
+        D = self.head_dim
+        return CompressedArena.prepare_extents([(p[0], p[2]) for p in pasts], compression.kth_from_sparsity(self.cfg.k_sparsity, D),
+                                               compression.kth_from_sparsity(self.cfg.v_sparsity, D))
+
+    def run_triggers(self, pasts, pool=None):
+        """The trigger (model :324-398) of every layer whose last step reached it (decode_fused(defer_trigger=True), or a replayed
+        graph of the step accounted with advance()): prune + compress the 256 oldest window rows of K and V into an extent of the
+        cache, slide the windows.  All layers in two library calls and one host read (cache.py: append_extent_pairs) where the cache
+        grows by extents; layer by layer otherwise.  Returns the new list of pasts."""
+        cfg, D = self.cfg, self.head_dim
+        kth_k, kth_v = compression.kth_from_sparsity(cfg.k_sparsity, D), compression.kth_from_sparsity(cfg.v_sparsity, D)
+        out = list(pasts)
+        due = [i for i, p in enumerate(pasts) if self.trigger_due(p)]
+        if not due:
+            return out
+        batch = [i for i in due if self._batched_ok(pasts[i])]
+        wl = {pasts[i][1].len for i in batch}
+        if batch and len(wl) == 1 and len({pasts[i][1].buf.shape for i in batch}) == 1:
+            CompressedArena.append_extent_pairs([(pasts[i][0], pasts[i][2]) for i in batch], [(pasts[i][1].buf, pasts[i][3].buf) for i in batch],
+                                                kth_k, kth_v, wl.pop(), pool if len(batch) == len(pasts) else None)
+            for i in batch:
+                k_c, k_w, v_c, v_w, C, L = pasts[i]
+                k_w.len = v_w.len = k_w.len - 256
+                out[i] = (k_c, k_w, v_c, v_w, C + 256, L)
+        else:
+            batch = []
+        for i in due:
+            if i in batch:
+                continue
+            k_c, k_w, v_c, v_w, C, L = pasts[i]
+            out[i] = self._trigger_one(k_c, k_w, v_c, v_w, C, L, kth_k, kth_v)
+        return out
+
+    def _trigger_one(self, k_c, k_w, v_c, v_w, C, L, kth_k, kth_v):
+        """One layer's trigger over an arena cache (the body decode_fused runs when it is not deferred)."""
+        cfg = self.cfg
+        groups = self.num_key_value_groups
+        flags = _lib.ENGINE_FLAGS[cfg.engine] | _lib.STRUCTURE_FLAGS[cfg.structure]
+        ld = (C + max(k_w.cap, v_w.cap) + 31) // 32 * 32
+        Lb = _lib.load()
+        if C == 0:
+            k_c, v_c = CompressedArena.from_raw_pair(k_w.buf, v_w.buf, 256, kth_k, kth_v, None, self._slack())
+            if cfg.extents:
+                k_c.ext_table, v_c.ext_table
+        elif cfg.extents and k_c.tokens % 256 == 0 and Lb.mustafar_decode_reads_extents(groups, ld, flags):
+            if len(k_c.extents) >= k_c.MAX_EXTENTS:          # table full: one copy of the cache, then extents again
+                k_c, v_c = k_c.consolidate(), v_c.consolidate()
+                k_c.ext_table, v_c.ext_table
+            CompressedArena.append_extent_pair(k_c, v_c, k_w.buf, v_w.buf, kth_k, kth_v)
+        else:
+            if k_c.extents:
+                k_c, v_c = k_c.consolidate(), v_c.consolidate()
+            CompressedArena.append_window_pair(k_c, v_c, k_w.buf, v_w.buf, 256, kth_k, kth_v)
+        Window.drop_front_pair(k_w, v_w, 256)                                                   # :392-393, in place
+        return (k_c, k_w, v_c, v_w, C + 256, L)
 
     # ---- decode (model :256-400) -----------------------------------------------------------------------------
     def decode(self, query_states, key_states, value_states, past, attention_mask=None):

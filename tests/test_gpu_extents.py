@@ -243,3 +243,75 @@ def test_left_padding_mask_across_a_trigger_with_extents():
         want = torch.matmul(torch.softmax(s, -1), V.float().repeat_interleave(hq // hkv, dim=1))
         torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3, msg=lambda m, step=step: f"step {step}: {m}")
     assert past[4] == 512 and len(past[0].extents) == 1
+
+
+@pytest.mark.parametrize("hq,hkv,prepared", [(8, 2, True), (8, 2, False), (8, 8, True)])
+def test_batched_trigger_of_all_layers_equals_the_layer_by_layer_trigger(hq, hkv, prepared):
+    """`run_triggers` (round 4): the trigger of every layer in two library calls and ONE host read, into a pooled allocation made ahead
+    (`prepare_triggers`).  Three layers with different data go through two triggers: every step's output, the caches in the
+    reference layout and the windows equal the layer-by-layer trigger that decode_fused runs itself, bit for bit."""
+    torch.manual_seed(12)
+    layers, bsz, D = 3, 2, 128
+    L0, steps = 256 + R + 250, 6 + 256 + 3
+    K0 = [torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(layers)]
+    V0 = [torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(layers)]
+    attn = _attn(hq, hkv)
+    ref_p = [attn.to_fused(attn.build_cache(K0[l].clone(), V0[l].clone())) for l in range(layers)]
+    bat_p = [attn.to_fused(attn.build_cache(K0[l].clone(), V0[l].clone())) for l in range(layers)]
+    fired = 0
+    for step in range(steps):
+        pool = None
+        qkv = [tuple(torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv)) for _ in range(layers)]
+        if prepared and (bat_p[0][5] + 1 - R - bat_p[0][4]) % 256 == 0 and bat_p[0][1].len + 1 >= 256:   # this step will reach the trigger
+            pool = attn.prepare_triggers(bat_p)
+            assert pool is not None
+        for l in range(layers):
+            o_ref, ref_p[l] = attn.decode(*qkv[l], ref_p[l])
+            o_bat, bat_p[l] = attn.decode_fused(*qkv[l], bat_p[l], defer_trigger=True)
+            assert torch.equal(o_ref, o_bat), f"step {step} layer {l}"
+        if attn.trigger_due(bat_p[0]):
+            fired += 1
+            assert all(attn.trigger_due(p) for p in bat_p)
+            bat_p = attn.run_triggers(bat_p, pool)
+        for l in range(layers):
+            assert bat_p[l][4] == ref_p[l][4] and bat_p[l][1].len == ref_p[l][1].len == bat_p[l][3].len
+    assert fired == 2 and all(len(p[0].extents) == 2 and p[0].total_tokens == 256 + 512 for p in bat_p)
+    for l in range(layers):
+        for side in (0, 2):
+            a, b = bat_p[l][side].to_reference(), ref_p[l][side].to_reference()
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+            assert torch.equal(torch.cat(list(a[2])), torch.cat(list(b[2])))
+        assert torch.equal(bat_p[l][1].view(), ref_p[l][1].view()) and torch.equal(bat_p[l][3].view(), ref_p[l][3].view())
+
+
+def test_batched_trigger_redoes_a_layer_whose_rows_are_full_of_ties():
+    """A layer whose 256 window rows keep EVERY value (all magnitudes equal: ties at the threshold are kept, model :107) outgrows the
+    pooled extent's region: its flag comes back set, it is redone on its own at the measured size (its raw rows are still in place:
+    nothing slides before every flag has been seen), the other layers are untouched -- and all equal the layer-by-layer trigger."""
+    torch.manual_seed(13)
+    layers, bsz, hq, hkv, D = 3, 1, 8, 2, 128
+    L0 = 256 + R + 255                                   # the first decode step reaches the trigger
+    K0 = [torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(layers)]
+    V0 = [torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(layers)]
+    sign = torch.where(torch.rand(bsz, hkv, 256, D, device=DEV) < 0.5, -1.0, 1.0).half()
+    K0[1][:, :, 256:512] = 0.5 * sign                    # layer 1: the rows of the coming trigger tie everywhere (K only)
+    attn = _attn(hq, hkv)
+    ref_p = [attn.to_fused(attn.build_cache(K0[l].clone(), V0[l].clone())) for l in range(layers)]
+    bat_p = [attn.to_fused(attn.build_cache(K0[l].clone(), V0[l].clone())) for l in range(layers)]
+    qkv = [tuple(torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv)) for _ in range(layers)]
+    for l in range(layers):
+        _, ref_p[l] = attn.decode(*qkv[l], ref_p[l])
+        _, bat_p[l] = attn.decode_fused(*qkv[l], bat_p[l], defer_trigger=True)
+    bat_p = attn.run_triggers(bat_p, attn.prepare_triggers(bat_p))
+    for l in range(layers):
+        assert bat_p[l][4] == ref_p[l][4] == 512 and len(bat_p[l][0].extents) == 1 and bat_p[l][1].len == ref_p[l][1].len == R
+        for side in (0, 2):
+            a, b = bat_p[l][side].to_reference(), ref_p[l][side].to_reference()
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(torch.cat(list(a[2])), torch.cat(list(b[2])))
+        assert torch.equal(bat_p[l][1].view(), ref_p[l][1].view())
+    assert int(bat_p[1][0].extents[0].used.max()) == 256 * 128       # every value of the tied rows was kept
+    q2 = [tuple(torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv)) for _ in range(layers)]
+    for l in range(layers):                               # and the caches decode alike afterwards
+        o_ref, _ = attn.decode(*q2[l], ref_p[l])
+        o_bat, _ = attn.decode(*q2[l], bat_p[l])
+        assert torch.equal(o_ref, o_bat)

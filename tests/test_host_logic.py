@@ -35,7 +35,7 @@ def test_cabi_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for s in syms:
         assert hasattr(raw, s), f"{s} not exported"
-    assert L.mustafar_abi_version() >= 103
+    assert L.mustafar_abi_version() >= 104
     # pure host helpers (no device access)
     s = L.mustafar_value_pick_split_k(128, 1, 7936, 256, 4)
     assert 1 <= s <= 31
@@ -81,7 +81,8 @@ def test_extent_arguments_are_validated_without_a_gpu():
     assert call(None, view, 512, one, one, 768) == 1
     assert call(view, view, 512, one, one, 512, t_dev=one) == 1   # a device-side T needs a capacity beyond the base tokens
     assert L.mustafar_decode_reads_extents(4, 8256, 0) == 1 and L.mustafar_decode_reads_extents(8, 8256, 0) == 1
-    assert L.mustafar_decode_reads_extents(1, 8256, 0) == 0 and L.mustafar_decode_reads_extents(2, 8256, 0) == 0    # G < 4 forms
+    assert L.mustafar_decode_reads_extents(1, 8256, 0) == 1 and L.mustafar_decode_reads_extents(2, 8256, 0) == 1    # MHA, GQA-2: the pair form since round 4
+    assert L.mustafar_decode_reads_extents(4, 32 * 5000, 0) == 0                                                 # rows beyond the row kernel's slab count
     assert L.mustafar_decode_reads_extents(4, 8256 + 8, 0) == 0                                                  # row pitch % 32
     assert L.mustafar_decode_reads_extents(4, 8256, 1 << 4) == 0 and L.mustafar_decode_reads_extents(4, 8256, 2 << 4) == 1   # two launches / one-pass asked for
     assert L.mustafar_decode_reads_extents(4, 8256, 1 << 6) == 0                                                 # undefined flag bits

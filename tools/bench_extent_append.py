@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Host + device cost of one 256-token trigger when the cache grows by extents (cache.py: append_extent_pair), c3 geometry:
-32 layers x (prune + compress 256 window rows of K and V into an extent each, one flag / length read, table entry)."""
+"""Host + device cost of one 256-token trigger of ALL layers when the cache grows by extents, c3 geometry (32 layers, 64 kv-heads):
+  per layer  (round 3)  32 x append_extent_pair: two allocations, one compression launch, one flag / length read, two table entries
+  batched    (round 4)  append_extent_pairs: one pooled allocation (made ahead by prepare_extents: timed apart), every layer's
+                        compression launched back to back by ONE library call, ONE host read, one launch per layer for table + slide
+Each line: wall ms of the 32-layer trigger (synchronised), and torch's allocator counters around it (segments the driver was asked for)."""
 import os
 import sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,15 +20,47 @@ for l in range(layers):
     for a in arenas[-1]: a.ext_table
 wk = [torch.randn(B, H, 288, D, device=dev).half() for _ in range(layers)]
 torch.cuda.synchronize()
+
+
+def segs():
+    st = torch.cuda.memory_stats(dev)
+    return st.get("segment.all.allocated", 0), st.get("num_alloc_retries", 0)
+
+
 for rep in range(3):
+    s0 = segs()
     t0 = time.perf_counter()
+    slow = (0.0, -1)
     for l in range(layers):
+        tl = time.perf_counter()
         CompressedArena.append_extent_pair(arenas[l][0], arenas[l][1], wk[l], wk[l], kth, kth)
+        slow = max(slow, (time.perf_counter() - tl, l))
     torch.cuda.synchronize()
-    print("append_extent_pair x32: %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+    s1 = segs()
+    print("            slowest layer of the repetition: layer %d, %.2f ms" % (slow[1], slow[0] * 1e3))
+    print("per layer : append_extent_pair x32: %.2f ms   (driver segments allocated during it: %d, allocator retries: %d)"
+          % ((time.perf_counter() - t0) * 1e3, s1[0] - s0[0], s1[1] - s0[1]))
+# what the FIRST batched trigger of a process pays beyond the later ones, taken apart: a one-layer rehearsal first
 import cProfile, pstats
+wins1 = [(wk[0].clone(), wk[0].clone())]
+torch.cuda.synchronize()
+t0 = time.perf_counter()
 pr = cProfile.Profile(); pr.enable()
-for l in range(layers):
-    CompressedArena.append_extent_pair(arenas[l][0], arenas[l][1], wk[l], wk[l], kth, kth)
+pool1 = CompressedArena.prepare_extents(arenas[:1], kth, kth)
+CompressedArena.append_extent_pairs(arenas[:1], wins1, kth, kth, 288, pool1)
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+print("batched   : one-layer rehearsal (first use in the process): %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(14)
+for rep in range(4):
+    wins = [(w.clone(), w.clone()) for w in wk]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pool = CompressedArena.prepare_extents(arenas, kth, kth)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    s0 = segs()
+    CompressedArena.append_extent_pairs(arenas, wins, kth, kth, 288, pool)
+    torch.cuda.synchronize()
+    s1 = segs()
+    print("batched   : append_extent_pairs x32: %.2f ms   (prepare_extents ahead: %.2f ms; driver segments allocated during the trigger: %d)"
+          % ((time.perf_counter() - t1) * 1e3, (t1 - t0) * 1e3, s1[0] - s0[0]))
