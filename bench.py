@@ -418,7 +418,7 @@ class Workload:
                                                                      "same graph (device-side T)" if one_graph else
                                                                      "graph recorded ahead" if ahead is not None and box["g"] is ahead[0] else "re-captured"))
             else:
-                if until_trigger() == 8:
+                if until_trigger() == 8 and box["reaches_trigger"]:   # (a leg that ends in front of the trigger prepares nothing: the work would sit in its timed region)
                     if box["next"] is None and not self.no_capture_ahead and not one_graph:
                         capture_ahead()
                     if "pool" not in box:
@@ -428,6 +428,7 @@ class Workload:
                 box["since"] += 1
 
         capture()
+        box["reaches_trigger"] = warmup + steps >= until_trigger()
         for _ in range(warmup):
             step()
         dt = self.bracket(lambda: [step() for _ in range(steps)])

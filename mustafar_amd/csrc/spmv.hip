@@ -1952,6 +1952,27 @@ __device__ __forceinline__ void coef_issue_at(u32x4 (&c)[G], const void* __restr
     }
 }
 
+// Coefficient rows that are NOT a fixed distance apart (the value entry point's probabilities: rows N * ldb halfs apart, a runtime
+// quantity): one base pointer per head, the offset inside the block still an immediate.
+template <int G>
+struct CoefPtrs {
+    const void* p[G];
+};
+template <int G, int OFF, int HS>
+__device__ __forceinline__ void coef_issue_at(u32x4 (&c)[G], const CoefPtrs<G>& cb)
+{
+    if constexpr (G == 4) {
+        asm volatile("s_load_dwordx4 %0, %4, %8\n\ts_load_dwordx4 %1, %5, %8\n\t"
+                     "s_load_dwordx4 %2, %6, %8\n\ts_load_dwordx4 %3, %7, %8"
+                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3])
+                     : "s"(cb.p[0]), "s"(cb.p[1]), "s"(cb.p[2]), "s"(cb.p[3]), "i"(OFF));
+    } else if constexpr (G == 2) {
+        asm volatile("s_load_dwordx4 %0, %2, %4\n\ts_load_dwordx4 %1, %3, %4" : "=&s"(c[0]), "=&s"(c[1]) : "s"(cb.p[0]), "s"(cb.p[1]), "i"(OFF));
+    } else {
+        asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(c[0]) : "s"(cb.p[0]), "i"(OFF));
+    }
+}
+
 struct Gathered2 {
     uint32_t t[8];   // gathered halfs, EXACT zero where the tile has no element in the lane: even tiles bits 15:0, odd tiles bits 31:16
 };
@@ -2101,9 +2122,9 @@ __device__ __forceinline__ uint32_t prefetch_meta_all(const uint64_t* __restrict
 // One staged chunk (32 tiles) of the lean kernel; the step schedule is chunk32's.
 //   bmp_t / idx_t : the BLOCK's bitmaps / offsets (the chunk starts TOFF tiles in);  cbase + COFF + h * HS : the chunk's first
 //   coefficient of head h
-template <int ENG, int TOFF, int COFF, int HS, int G = 4>
+template <int ENG, int TOFF, int COFF, int HS, int G = 4, class CB = const void*>   // CB: const void* (rows HS bytes apart) or CoefPtrs<G>
 __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
-                                           const void* __restrict__ cbase, float (&acc)[G])
+                                           const CB& cbase, float (&acc)[G])
 {
     static_assert(G == 4 || ENG == 0, "dot2 pairs four heads' coefficients; G < 4 runs v_fma_mix");
     // (with the coefficients in scalar registers as well, an early request leaves the loop 140+ registers short of the 78 a wave of
@@ -2156,10 +2177,10 @@ __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restr
 //   VAL = true  (value): chunks 0, 1 -> accA (channels 0..63), chunks 2, 3 -> accB (channels 64..127), lane = channel;
 //                        coefficient of a tile: the row's half (token % 64)
 //   bnd: the block's five chunk bounds (bnd_load), fetched by the caller ahead of time
-template <int ENG, int HS, bool VAL, int CB, int CN, int G = 4>   // chunks [CB, CB + CN) of the block; G heads (G < 4: ENG 0)
+template <int ENG, int HS, bool VAL, int CB, int CN, int G = 4, class CBT = const void*>   // chunks [CB, CB + CN) of the block; G heads (G < 4: ENG 0)
 __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t lds_addr, const uint64_t* __restrict__ bmp_t,
                                                  const uint32_t* __restrict__ idx_t, const unsigned char* __restrict__ nz_h,
-                                                 const void* __restrict__ cbase, uint32_t bnd, int lane, float (&accA)[G],
+                                                 const CBT& cbase, uint32_t bnd, int lane, float (&accA)[G],
                                                  float (&accB)[G]
 #ifdef MUSTAFAR_WAVE_TRACE
                                                  , PhaseTrace& phase_trace_
@@ -2201,10 +2222,10 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
             else if (c == 2) chunk32_mfma_at<64, VAL ? 0 : 128>(adj, bmp_t, idx_t, ctab_lane, VAL ? mB : mA);
             else             chunk32_mfma_at<96, VAL ? 64 : 192>(adj, bmp_t, idx_t, ctab_lane, VAL ? mB : mA);
         } else {
-            if (c == 0)      chunk32_at<ENG, 0, 0, HS, G>(adj, bmp_t, idx_t, cbase, accA);
-            else if (c == 1) chunk32_at<ENG, 32, 64, HS, G>(adj, bmp_t, idx_t, cbase, accA);
-            else if (c == 2) chunk32_at<ENG, 64, VAL ? 0 : 128, HS, G>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
-            else             chunk32_at<ENG, 96, VAL ? 64 : 192, HS, G>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
+            if (c == 0)      chunk32_at<ENG, 0, 0, HS, G, CBT>(adj, bmp_t, idx_t, cbase, accA);
+            else if (c == 1) chunk32_at<ENG, 32, 64, HS, G, CBT>(adj, bmp_t, idx_t, cbase, accA);
+            else if (c == 2) chunk32_at<ENG, 64, VAL ? 0 : 128, HS, G, CBT>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
+            else             chunk32_at<ENG, 96, VAL ? 64 : 192, HS, G, CBT>(adj, bmp_t, idx_t, cbase, VAL ? accB : accA);
         }
         __builtin_amdgcn_wave_barrier();
         if (c < CB + CN - 1) {
@@ -2633,6 +2654,203 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     MUSTAFAR_PTRACE_END(7);
 }
 
+// ------------------------------------------------------------------------------------------------ key SpMV, lean pair form (round 4)
+// The reference entry point Key_SplitK_API (kernel/csrc/SpMM_API.cu:86-139 -> Key_Kernel, SpMM_Kernel.cuh:156-419) on the machinery
+// of the one-pass launch's key phase: two waves share a 64-token block (64 channels each, partial scores folded through LDS), every
+// address inside the block is one base pointer + an immediate (lean_block_phase), the stream loads are non-temporal, the launch is
+// compiled for 8 waves per SIMD.  Exact products only (v_fma_mix, or the matrix pipe for four heads): this is what an unchanged hook
+// calls.  N = rows per head of the dense operand: 1, or the hook's 8 (llama_mustafar_kernel.py:273: rows 1..7 are zero padding and
+// are written as exact zeros unless a row holds a non-zero, in which case it is computed like row 0).
+template <int G, int ENG, int N>
+__global__ MUSTAFAR_LP_BOUNDS void key_lean_kernel(
+    const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
+    const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int groups, int ldc, WinArgs wa,
+    int64_t bmp_stride, int64_t idx_stride, uint32_t nz_stride)
+{
+    static_assert(ENG == 0 || (ENG == 1 && G == 4), "exact products: v_fma_mix, or the matrix pipe for four heads");
+    constexpr int kTabBytes = ENG == 1 ? 4 * kKeyTabStride : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
+    MUSTAFAR_TRACE_BEGIN(1);
+    MUSTAFAR_PTRACE_BEGIN();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wrows = wa.rows < 0 ? -wa.rows : wa.rows;            // window rows lead (rows > 0) or trail (rows < 0) the grid
+    const int wy = wa.rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
+    if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window scores
+        const int task = wy * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wrows) * wa.nchunks)
+            key_window_wg<G>(smem, q, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, out, T, ldc,
+                             groups, task);
+        MUSTAFAR_TRACE_END();
+        return;
+    }
+    const int by = blockIdx.y - (wa.rows > 0 ? wa.rows : 0);
+    const int hb_per_kv = groups / G;
+    const int kvh = by / hb_per_kv;
+    const int bh0 = kvh * groups + (by % hb_per_kv) * G;
+    const int ntb = T >> 6;
+    const int pair = wave >> 1;
+    const bool odd = wave & 1;
+    const int tb = blockIdx.x * 2 + pair;
+    const bool active = tb < ntb;                                   // (wave-uniform)
+    const int tbc = active ? tb : ntb - 1;
+    const int64_t tiles = (int64_t)ntb * kTilesPerTb;
+    const uint64_t* kbt = bmp + (int64_t)kvh * (bmp_stride ? bmp_stride : tiles) + (int64_t)tbc * kTilesPerTb;
+    const uint32_t* kit = idx + (int64_t)kvh * (idx_stride ? idx_stride : tiles + 1) + (int64_t)tbc * kTilesPerTb;
+    const unsigned char* kn = nz + 16ull * (nz_stride ? (uint64_t)kvh * nz_stride : (uint64_t)nz_off[kvh]);
+    unsigned char* lds = smem + wave * kStageBytes;
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    float* xch_out = reinterpret_cast<float*>(lds);                                        // odd wave: [G][64] partial scores for the even wave
+    const float* xch_in = reinterpret_cast<const float*>(smem + (wave | 1) * kStageBytes);
+
+    uint32_t rows = 1u;   // bit n: row n has to be computed
+    if constexpr (N > 1) rows |= pad_row_mask<G>(q, kD, bh0, N, 0, kD, reinterpret_cast<uint32_t*>(smem));
+    const int tok0 = blockIdx.x * 128;
+    const int ntok = min(128, T - tok0);
+    uint32_t bnd = 0;
+    if (active) bnd = bnd_load(kit, lane);                          // (the same five chunk bounds for every row)
+#pragma unroll 1
+    for (int n = 0; n < N; n++) {
+        if ((rows >> n) & 1u) {
+            const h16* qb = q + ((int64_t)bh0 * N + n) * kD;        // the G rows, N * 256 bytes apart
+            uint32_t ctab_q = 0;
+            if constexpr (ENG == 1) {   // coefficient table: row n of the 4 heads, 16 bytes per thread
+                unsigned char* tab = smem + kWaves * kStageBytes;
+                if (n > 0) __syncthreads();
+                if (threadIdx.x < 64)
+                    *reinterpret_cast<uint4*>(tab + (threadIdx.x >> 4) * kKeyTabStride + (threadIdx.x & 15) * 16) =
+                        *reinterpret_cast<const uint4*>(qb + (int64_t)(threadIdx.x >> 4) * N * kD + (threadIdx.x & 15) * 8);
+                __syncthreads();
+                ctab_q = (uint32_t)reinterpret_cast<uintptr_t>(tab) + (lane & 3) * kKeyTabStride;
+            }
+            float s[G];
+#pragma unroll
+            for (int h = 0; h < G; h++) s[h] = 0.f;
+            if (active) {
+                const uint32_t pf = odd ? prefetch_meta_all<64, 64>(kbt, kit, lane) : prefetch_meta_all<0, 64>(kbt, kit, lane);
+                if (odd) lean_block_phase<ENG, N * kD * 2, false, 2, 2, G>(lds, lds_addr, kbt, kit, kn, qb, bnd, lane, s, s MUSTAFAR_PTRACE_ARG, ctab_q);
+                else     lean_block_phase<ENG, N * kD * 2, false, 0, 2, G>(lds, lds_addr, kbt, kit, kn, qb, bnd, lane, s, s MUSTAFAR_PTRACE_ARG, ctab_q);
+                prefetch_done(pf);
+                if (odd) {
+#pragma unroll
+                    for (int h = 0; h < G; h++) xch_out[h * 64 + lane] = s[h];
+                }
+            }
+            __syncthreads();
+            if (active && !odd) {
+#pragma unroll
+                for (int h = 0; h < G; h++)
+                    out[((int64_t)(bh0 + h) * N + n) * ldc + (int64_t)tb * 64 + lane] = (h16)(s[h] + xch_in[h * 64 + lane]);
+            }
+            if constexpr (N > 1) __syncthreads();   // the exchange areas are stage windows again in the next row
+        } else {   // exact zeros, 16 bytes per lane
+            const int per_row = ntok / 8;
+            const uint4 z = {0u, 0u, 0u, 0u};
+            for (int u = threadIdx.x; u < G * per_row; u += kThreads) {
+                const int h = u / per_row, k = u % per_row;
+                *reinterpret_cast<uint4*>(out + ((int64_t)(bh0 + h) * N + n) * ldc + tok0 + k * 8) = z;
+            }
+        }
+    }
+    MUSTAFAR_TRACE_END();
+}
+
+// ------------------------------------------------------------------------------------------------ value SpMV, lean pair form (round 4)
+// The reference entry point Value_SplitK_API (kernel/csrc/SpMM_API.cu:193-254 -> Value_Kernel, SpMM_Kernel.cuh:421-676) on the
+// machinery of the one-pass launch's value phase: two waves share a 64-token block (one 64-channel half of the output each), a
+// workgroup (two pairs) walks its token chunk two blocks at a time, every address inside a block is a base pointer + an immediate
+// (one pointer per head for the probabilities: their rows are N * ldb halfs apart, a runtime quantity), non-temporal stream loads,
+// 8 waves per SIMD, issue priority by progress.  v_fma_mix: exact products.  Slabs, flags and the combine pass as value_spmv_kernel.
+template <int G, int N>
+__global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
+    const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
+    const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
+    uint32_t* __restrict__ flags, int T, int groups, int BH, int tb_per_wg, int direct, int ldb, WinArgs wa,
+    int64_t bmp_stride, int64_t idx_stride, uint32_t nz_stride)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes];
+    static_assert(kWaves * kStageBytes >= kWaves * G * 64 * 4, "reduce buffer must fit in the stage area");
+    MUSTAFAR_TRACE_BEGIN(2);
+    MUSTAFAR_PTRACE_BEGIN();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wrows = wa.rows < 0 ? -wa.rows : wa.rows;            // window rows lead (rows > 0) or trail (rows < 0) the grid
+    const int wy = wa.rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
+    if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window p.V -> slabs gridDim.x ..
+        const int task = wy * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wrows) * wa.nchunks)
+            value_window_wg<G, kWaves>(smem, p, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, ws,
+                                       (int64_t)BH * kD, gridDim.x, T, ldb, groups, task);
+        MUSTAFAR_TRACE_END();
+        return;
+    }
+    const int by = blockIdx.y - (wa.rows > 0 ? wa.rows : 0);
+    const int hb_per_kv = groups / G;
+    const int kvh = by / hb_per_kv;
+    const int bh0 = kvh * groups + (by % hb_per_kv) * G;
+    const int ntb = T >> 6;
+    const int tb0 = blockIdx.x * tb_per_wg;
+    const int tb_end = min(ntb, tb0 + tb_per_wg);
+    const int64_t tiles = (int64_t)ntb * kTilesPerTb;
+    const int pair = wave >> 1;
+    const bool odd = wave & 1;
+    const uint64_t* vb = bmp + (int64_t)kvh * (bmp_stride ? bmp_stride : tiles);
+    const uint32_t* vi = idx + (int64_t)kvh * (idx_stride ? idx_stride : tiles + 1);
+    const unsigned char* vn = nz + 16ull * (nz_stride ? (uint64_t)kvh * nz_stride : (uint64_t)nz_off[kvh]);
+    unsigned char* lds = smem + wave * kStageBytes;
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    float* red = reinterpret_cast<float*>(smem);   // [kWaves][G][64], overlays the stage windows
+    float* ws_slab = ws + (int64_t)blockIdx.x * BH * N * kD;
+
+    uint32_t rows = 1u;
+    if constexpr (N > 1) {
+        rows |= pad_row_mask<G>(p, ldb, bh0, N, tb0 * 64, (tb_end - tb0) * 64, reinterpret_cast<uint32_t*>(smem));
+        if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + by] = rows;   // (no window rows when N > 1)
+    }
+#pragma unroll 1
+    for (int n = 0; n < N; n++) {
+        const bool live = (rows >> n) & 1u;
+        if (!live && !direct) continue;   // the combine pass skips this row of this slab
+        float acc[G];
+#pragma unroll
+        for (int h = 0; h < G; h++) acc[h] = 0.f;
+        if (live) {
+            if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+            for (int t = tb0; t < tb_end; t += kWaves / 2) {
+                const int tb = t + pair;
+                if (tb < tb_end) {   // (wave-uniform; no barrier inside the loop: the pairs run freely)
+                    const uint64_t* vbt = vb + (int64_t)tb * kTilesPerTb;
+                    const uint32_t* vit = vi + (int64_t)tb * kTilesPerTb;
+                    const uint32_t bnd = bnd_load(vit, lane);
+                    const uint32_t pf = odd ? prefetch_meta_all<64, 64>(vbt, vit, lane) : prefetch_meta_all<0, 64>(vbt, vit, lane);
+                    CoefPtrs<G> cb;
+#pragma unroll
+                    for (int h = 0; h < G; h++) cb.p[h] = p + ((int64_t)(bh0 + h) * N + n) * ldb + (int64_t)tb * 64;
+                    if (odd) lean_block_phase<0, 0, true, 2, 2, G, CoefPtrs<G>>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG);
+                    else     lean_block_phase<0, 0, true, 0, 2, G, CoefPtrs<G>>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG);
+                    prefetch_done(pf);
+                }
+                if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(0);   // (the first block is done)
+            }
+        }
+        __syncthreads();   // every wave is done with its stage window (and with the previous row's sums)
+#pragma unroll
+        for (int h = 0; h < G; h++) red[(wave * G + h) * 64 + lane] = acc[h];
+        __syncthreads();
+        for (int o = threadIdx.x; o < 2 * G * 64; o += kThreads) {
+            const int hh = o >> 6, l = o & 63;   // hh = half * G + h; waves `half` and `half + 2` hold that half
+            const int half = hh / G, h = hh % G;
+            const float sum = red[(half * G + h) * 64 + l] + red[((half + 2) * G + h) * 64 + l];
+            const int64_t row = (int64_t)(bh0 + h) * N + n;
+            if (direct) out[row * kD + half * 64 + l] = (h16)sum;
+            else        ws_slab[row * kD + half * 64 + l] = sum;
+        }
+        if constexpr (N > 1) __syncthreads();
+    }
+    MUSTAFAR_TRACE_END();
+}
+
 inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : 1; }
 
 // FMA engine of the G = 4 kernels: 2 = v_dot2_f32_f16 on pairs of tiles (the DEFAULT: one-pass launch only; the two reference
@@ -2640,6 +2858,15 @@ inline int pick_g(int groups) { return (groups % 4 == 0) ? 4 : (groups % 2 == 0)
 // included; MUSTAFAR_FMA_ENGINE=valu), 1 = matrix pipe as a 4-wide FMA unit (v_mfma_f32_4x4x4_16B_f16; opt-in, MFMA left off by
 // default as the north_star asks: MUSTAFAR_FMA_ENGINE=mfma or mustafar_set_fma_engine(1)).
 inline int fma_engine();
+int g_key_lean = -1;    // the two reference entry points on the lean pair machinery (round 4): MUSTAFAR_KEY_LEAN / MUSTAFAR_VALUE_LEAN = 0 | 1
+inline bool key_lean()
+{
+    if (g_key_lean < 0) {
+        const char* e = getenv("MUSTAFAR_KEY_LEAN");
+        g_key_lean = e ? atoi(e) != 0 : 1;
+    }
+    return g_key_lean != 0;
+}
 int g_key_split = -1;   // 0 = automatic; MUSTAFAR_KEY_SPLIT=1|2 forces
 inline int key_split(int ntb, int gy)
 {
@@ -2771,6 +2998,29 @@ void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, co
     const int G = pick_g(groups);
     const int gy = (Batch_Size / groups) * (groups / G);
     const int ntb = T / 64;
+    if (key_lean() && (N == 1 || N == 8)) {
+        // round 4: the lean pair form (key_lean_kernel); MUSTAFAR_KEY_LEAN=0 / mustafar_tune(6, 0) selects the round-1 kernel below
+        dim3 grid((ntb + 1) / 2, gy);
+        if (wa.win) {
+            wa.nchunks = (wa.w_cap + kKeyWinChunk - 1) / kKeyWinChunk;
+            wa.rows = (gy * wa.nchunks + (int)grid.x - 1) / (int)grid.x;
+            grid.y += wa.rows;
+            if (window_rows_last(0)) wa.rows = -wa.rows;
+        }
+        const bool mf = G == 4 && fma_engine() == 1;
+#define MUSTAFAR_LKL(GG, EE)                                                                                                     \
+    do {                                                                                                                         \
+        if (N == 1) hipExtLaunchKernelGGL((key_lean_kernel<GG, EE, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, q, out,   \
+                                          T, groups, ldc, wa, bmp_stride, idx_stride, nz_stride);                                \
+        else        hipExtLaunchKernelGGL((key_lean_kernel<GG, EE, 8>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, q, out,   \
+                                          T, groups, ldc, wa, bmp_stride, idx_stride, nz_stride);                                \
+    } while (0)
+        if (G == 4) { if (mf) MUSTAFAR_LKL(4, 1); else MUSTAFAR_LKL(4, 0); }
+        else if (G == 2) MUSTAFAR_LKL(2, 0);
+        else MUSTAFAR_LKL(1, 0);
+#undef MUSTAFAR_LKL
+        return;
+    }
     const int split = key_split(ntb, gy);
     const int per_wg = kWaves / split;
     dim3 grid((ntb + per_wg - 1) / per_wg, gy);
@@ -2811,7 +3061,21 @@ inline int value_split()
     if (g_value_split) return g_value_split;
     return fma_engine() == 1 ? 1 : 2;   // the MFMA form needs > 80 VGPRs: 8-wave workgroups would drop to 4 waves per SIMD
 }
-inline int value_tb_stride() { return value_split() == 2 ? kValueWaves / 2 : kWaves; }   // token blocks in flight per workgroup
+// round 4: the lean pair form of the value entry point (value_lean_kernel, v_fma_mix engine) is OPT-IN -- MUSTAFAR_VALUE_LEAN=1 /
+// mustafar_tune(7, 1).  Measured against value_spmv_kernel (kernel + combine, us, N = 1): c3 28.0-29.9 vs 29.4-30.1, c4 48.8 vs 46.7,
+// c5 85.6 vs 76.8; N = 8 (the hook's padded rows): c3 55.7 vs 41.2 -- the round-1 kernel keeps its next block's bounds, metadata lines
+// and first chunk in flight while it works on the current one, which a value-only launch (no softmax step between the blocks) can do
+// and the lean block phase does not; lean addressing alone does not make up for it (profiles/r04_probes.txt).
+int g_value_lean = -1;
+inline bool value_lean()
+{
+    if (g_value_lean < 0) {
+        const char* e = getenv("MUSTAFAR_VALUE_LEAN");
+        g_value_lean = e ? atoi(e) != 0 : 0;
+    }
+    return g_value_lean != 0 && fma_engine() != 1;
+}
+inline int value_tb_stride() { return value_lean() ? kWaves / 2 : value_split() == 2 ? kValueWaves / 2 : kWaves; }   // token blocks in flight per workgroup
 
 // One place that picks the value kernel instantiation.
 void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned char* nz, const uint32_t* idx,
@@ -2825,6 +3089,20 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
         wa.rows = ((int)grid.y * wa.nchunks + (int)grid.x - 1) / (int)grid.x;
         grid.y += wa.rows;
         if (window_rows_last(1)) wa.rows = -wa.rows;
+    }
+    if (value_lean() && (N == 1 || N == 8)) {
+#define MUSTAFAR_LVL(GG)                                                                                                         \
+    do {                                                                                                                         \
+        if (N == 1) hipExtLaunchKernelGGL((value_lean_kernel<GG, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,  \
+                                          flags, T, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride);            \
+        else        hipExtLaunchKernelGGL((value_lean_kernel<GG, 8>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,  \
+                                          flags, T, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride);            \
+    } while (0)
+        if (G == 4) MUSTAFAR_LVL(4);
+        else if (G == 2) MUSTAFAR_LVL(2);
+        else MUSTAFAR_LVL(1);
+#undef MUSTAFAR_LVL
+        return;
     }
 #define MUSTAFAR_LV(GG, MFF)                                                                                                   \
     do {                                                                                                                       \
@@ -3322,6 +3600,8 @@ int mustafar_tune(int knob, int value)
         case 2: g_onepass_wgs = value; return 0;
         case 3: g_lean_win_last = value ? 1 : 0; return 0;
         case 4: g_pair_slabs = value ? 1 : 0; return 0;
+        case 6: g_key_lean = value ? 1 : 0; return 0;
+        case 7: g_value_lean = value ? 1 : 0; return 0;
         default: return MUSTAFAR_EINVAL;
     }
 }
