@@ -508,10 +508,11 @@ def run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib):
         raise SystemExit(f"bench.py: self-check FAILED at {name}: fused vs reference entry points, {excess:.2f}x the fp16 bound")
     steps = max(3, a.steps // 2)
     dt, (ku, vu, n) = w.timed_graph(steps, 2)
-    rl = w.roofline(ku, vu, n, traffic_file=False)
+    rl = w.roofline(ku, vu, n)
     out = {"workload": w.label, "value": round(world * w.batch * steps / dt, 2), "unit": "tokens/s", "ms_per_step": round(dt / steps * 1e3, 4),
            "steps": steps, "self_check_excess": round(excess, 3),
-           "kernel": rl["kernel"], "kernel_us": rl["avg_launch_us"], "roofline_frac": rl["frac"], "roofline_achieved_GBps": rl["achieved"], "kv_bytes_reference_layout": int(w.ref_kv_bytes), "dense_kv_bytes": int(w.dense_bytes),
+           "kernel": rl["kernel"], "kernel_us": rl["avg_launch_us"], "roofline_frac": rl["frac"], "roofline_achieved_GBps": rl["achieved"],
+           "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"], "traffic": rl["traffic"], "kv_bytes_reference_layout": int(w.ref_kv_bytes), "dense_kv_bytes": int(w.dense_bytes),
            "arena_bytes_in_use": w.extra.get("arena_bytes_in_use"), "arena_bytes_reserved": w.extra.get("arena_bytes_reserved")}
     if (w.Hq // w.Hkv) % 4 == 0:   # the same leg on the other two engines (GQA-4 kernels only), chosen per instance (cfg.engine -> flags)
         for eng, key in (("valu", "fma_engine_fma_mix"), ("mfma", "fma_engine_mfma")):
