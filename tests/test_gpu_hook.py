@@ -150,8 +150,9 @@ print("alt-form ok")
 @pytest.mark.parametrize("env", [{"MUSTAFAR_ONEPASS": "0"}, {"MUSTAFAR_ONEPASS": "1"}, {"MUSTAFAR_ONEPASS": "1", "MUSTAFAR_FMA_ENGINE": "mfma"},
                                  {"MUSTAFAR_ONEPASS": "1", "MUSTAFAR_ONEPASS_WGS": "7"},
                                  {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_WINDOW": "rows"}, {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_WINDOW": "key"},
-                                 {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_VALUE_SPLIT": "1"}, {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_KEY_SPLIT": "1"},
-                                 {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_KEY_SPLIT": "2", "MUSTAFAR_FMA_ENGINE": "mfma"},
+                                 {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_VALUE_SPLIT": "1"}, {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_KEY_LEAN": "0", "MUSTAFAR_KEY_SPLIT": "1"},
+                                 {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_KEY_LEAN": "0", "MUSTAFAR_KEY_SPLIT": "2", "MUSTAFAR_FMA_ENGINE": "mfma"},
+                                 {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_KEY_LEAN": "0"}, {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_VALUE_LEAN": "1"},
                                  {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_WINDOW_POS": "first"}, {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_WINDOW_POS": "last"}])
 def test_alternative_kernel_forms_in_a_child_process(env):
     """The launch-shape switches are read once per process: each form -- the one-pass launch and the two-launch form with

@@ -24,14 +24,20 @@ def pkg():
     return mustafar_package, compression
 
 
-@pytest.fixture(params=["valu", "mfma"], autouse=True)
+@pytest.fixture(params=["valu", "mfma", "valu-other-forms"], autouse=True)
 def fma_engine(request):
-    """Every test of this module runs on both FMA engines of the GQA-4 kernels."""
+    """Every test of this module runs on both FMA engines of the GQA-4 kernels, and once more with the kernel forms
+    that are NOT the default of the two entry points (round 4: the key entry point defaults to the lean pair kernel, the value entry
+    point to round 1's kernel; mustafar_tune(6 / 7) select the other one of each)."""
     from mustafar_amd import _lib
     L = _lib.load()
     assert L.mustafar_set_fma_engine(1 if request.param == "mfma" else 0) == 0
+    other = request.param.endswith("other-forms")
+    assert L.mustafar_tune(6, 0 if other else 1) == 0 and L.mustafar_tune(7, 1 if other else 0) == 0
     yield request.param
-    L.mustafar_set_fma_engine(2)   # the process default
+    L.mustafar_set_fma_engine(2)   # the process defaults
+    L.mustafar_tune(6, 1)
+    L.mustafar_tune(7, 0)
 
 
 def _t(a, dtype=None):

@@ -46,4 +46,6 @@ MUSTAFAR_FMA_ENGINE=mfma python3 tools/microbench.py --cfg c3 c3 c4 c5 --rows 1 
 python3 tools/quick.py --cfg c2 c3 c4 c5 --set dot2 valu mfma valu:onepass=0 valu:lean=0 dot2:tbw=2 mfma:tbw=2 2> $O/quick.err | grep cfg > $O/structures.txt
 python3 tools/quick.py --cfg m8 g2 t8192 t8448 --set dot2 valu:onepass=0 2>> $O/quick.err | grep cfg >> $O/structures.txt
 python3 tools/bench_extent_append.py 2> $O/extent_append.err > $O/extent_append.txt; nonempty $O/extent_append.txt
+# only the summaries travel back (gpurun merges at most 64 MiB): the profiler's raw directories are dropped
+rm -rf $R/gpurun_out/pmc_${TAG}_* $R/gpurun_out/traffic_${TAG}_* $O/rocprof_bench
 echo "all done"; ls $O

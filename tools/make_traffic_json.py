@@ -18,14 +18,14 @@ for tag, cname in (("F", "FETCH_SIZE"), ("W", "WRITE_SIZE")):
     acc = {}
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        for name in ("key_spmv_kernel", "value_spmv_kernel", "decode_onepass"):
+        for name in ("key_spmv_kernel", "key_lean_kernel", "value_spmv_kernel", "value_lean_kernel", "decode_onepass_leanpair", "decode_onepass_kernel"):
             if name in k and r["Counter_Name"] == cname:
                 acc.setdefault(name, []).append(float(r["Counter_Value"]) * 1024)
     for name, v in acc.items():
         res.setdefault(name, {})[cname] = sum(v) / len(v)
 entry = {}
 for name, d in res.items():
-    short = "onepass" if name.startswith("decode_onepass") else name.split("_")[0]
+    short = "onepass" if name.startswith("decode_onepass") else name.split("_")[0]   # (key_lean_kernel and key_spmv_kernel never run in one collection)
     entry[short] = int(2 * d["FETCH_SIZE"] + d["WRITE_SIZE"])
     entry[short + "_raw"] = {"FETCH_SIZE_bytes": int(d["FETCH_SIZE"]), "WRITE_SIZE_bytes": int(d["WRITE_SIZE"])}
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "hbm_traffic.json")
