@@ -315,3 +315,17 @@ def test_batched_trigger_redoes_a_layer_whose_rows_are_full_of_ties():
         o_ref, _ = attn.decode(*q2[l], ref_p[l])
         o_bat, _ = attn.decode(*q2[l], bat_p[l])
         assert torch.equal(o_ref, o_bat)
+
+
+def test_a_device_side_T_needs_the_step_counter():
+    """`t_device` sizes the launch for a capacity and is meant for captured graphs: an eager call (no `step_counter`) is refused with a
+    clear error instead of launching at the capacity (and contradicting the eager mask-length check)."""
+    torch.manual_seed(14)
+    bsz, hq, hkv, D = 1, 8, 2, 128
+    K0, V0 = (torch.randn(bsz, hkv, 256 + R + 10, D, device=DEV).half() for _ in range(2))
+    attn = _attn(hq, hkv)
+    past = attn.to_fused(attn.build_cache(K0, V0))
+    q, k, v = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+    t_dev = torch.tensor([256], dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError, match="step_counter"):
+        attn.decode_fused(q, k, v, past, t_device=t_dev, t_capacity=512)

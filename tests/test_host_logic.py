@@ -88,6 +88,37 @@ def test_extent_arguments_are_validated_without_a_gpu():
     assert L.mustafar_decode_reads_extents(4, 8256, 1 << 6) == 0                                                 # undefined flag bits
 
 
+def test_batched_trigger_arguments_are_validated_without_a_gpu():
+    """mustafar_trigger_compress_batch / mustafar_trigger_finish_batch (round 4): every item is checked on the host before anything is
+    launched -- null windows, views without room for the 256 tokens, a missing flag, shapes."""
+    from mustafar_amd import _lib
+    L = _lib.load()
+    one = 8   # never dereferenced: validation fails first
+    good = _lib.CacheView(one, one, one, one, 2 * 256, 2 * 256 + 1, 4096)
+    short = _lib.CacheView(one, one, one, one, 2 * 192, 2 * 192 + 1, 4096)
+    def items(**kw):
+        arr = (_lib.TriggerItem * 2)()
+        for it in arr:
+            it.k_window = it.v_window = one
+            it.k_dst, it.v_dst = good, good
+            it.k_head_total = it.v_head_total = it.overflow_flag = one
+        for k, v in kw.items():
+            setattr(arr[1], k, v)
+        return arr
+    args = (288 * 128, 8, 256, 128, 89, 89, 32768, 32768, one)
+    assert L.mustafar_trigger_compress_batch(None, 0, items(), *args) == 1                       # no items
+    assert L.mustafar_trigger_compress_batch(None, 2, None, *args) == 1
+    assert L.mustafar_trigger_compress_batch(None, 2, items(k_window=None), *args) == 1          # second item: null window
+    assert L.mustafar_trigger_compress_batch(None, 2, items(overflow_flag=None), *args) == 1     # the flag is required
+    assert L.mustafar_trigger_compress_batch(None, 2, items(v_dst=short), *args) == 1            # rows too short for 256 tokens
+    assert L.mustafar_trigger_compress_batch(None, 2, items(), 100 * 128, *args[1:]) == 1        # window rows shorter than t
+    assert L.mustafar_trigger_compress_batch(None, 2, items(), *(args[:2] + (200,) + args[3:])) == 1   # t % 64
+    assert L.mustafar_trigger_compress_batch(None, 2, items(), *(args[:-1] + (None,))) == 1      # no scratch
+    assert L.mustafar_trigger_finish_batch(None, 2, items(v_window=None), 288 * 128, 8, 288, 256) == 1
+    assert L.mustafar_trigger_finish_batch(None, 2, items(), 288 * 128, 8, 200, 256) == 1        # len < drop
+    assert L.mustafar_trigger_finish_batch(None, 2, items(), 288 * 128, 8, 400, 256) == 1        # more than 64 rows would stay / beyond the stride
+
+
 def test_invalid_arguments_are_rejected_without_a_gpu():
     """Shape errors are caught on the host before any launch (MUSTAFAR_EINVAL == 1)."""
     from mustafar_amd import _lib
@@ -222,5 +253,11 @@ def test_stream_pieces_make_the_hooks_torch_cat_free():
     again = torch.cat(merged)
     assert again.data_ptr() == merged[0].data_ptr() and again.numel() == 64
     assert torch.equal(again, torch.cat([m.as_subclass(torch.Tensor).clone() for m in merged]))
+    # the same per-head concatenation asked for a SECOND time: a fresh tensor (the slot of the shared buffer belongs to the first
+    # result, which aliases the cache -- INTEGRATION.md "Aliasing"); an in-place op on it leaves the first result alone
+    twice = torch.cat([ps[0], new[0]], dim=0)
+    assert twice.data_ptr() != merged[0].data_ptr() and torch.equal(twice.as_subclass(torch.Tensor), merged[0].as_subclass(torch.Tensor))
+    twice.as_subclass(torch.Tensor).zero_()
+    assert float(merged[0][0]) == 0.0 and float(merged[0][1]) == 1.0 and float(again[1]) == 1.0
     # ordinary tensor behaviour of a piece
     assert float(ps[0][-1]) == 7.0 and type(ps[2] * 2) is torch.Tensor and ps[3].view(2, 8).shape == (2, 8) and len(ps[2]) == 16
