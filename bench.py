@@ -448,7 +448,7 @@ class Workload:
         kern = self.profile(lambda: [self.one_step(state) for _ in range(nprof)], nprof * layers)
         self.extra["triggers_in_timed_region"] = box["triggers"]
         if box["triggers"] and hasattr(state[0][0], "consolidate") and state[0][0].extents:
-            # what a full extent table (64 triggers) costs: every layer's base + extents re-housed into one base (a copy of the cache)
+            # what consolidation costs (a launch form that cannot read extents; a full table: 512 triggers): every layer's base + extents re-housed into one base
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             merged = [(p[0].consolidate(), p[2].consolidate()) for p in state]
@@ -668,7 +668,7 @@ def main():
                 "triggers": w.extra.get("triggers_in_timed_region"),
                 "trigger_step_ms": w.extra.get("trigger_step_ms"),
                 "consolidate_ms": w.extra.get("consolidate_ms"),
-                "consolidate_ms_note": "all 32 layers' K and V caches (base + the extent of this leg) re-housed into one base each: what a full extent table costs once per 64 triggers",
+                "consolidate_ms_note": "all 32 layers' K and V caches (base + the extent of this leg) re-housed into one base each: what a switch to a launch form that cannot read extents (or a full table: 512 triggers) costs",
                 "trigger_step_ms_note": "(the step's decode replayed from the graph + prune/compress of 256 tokens per head into an extent for ALL layers from two library calls and one host read, switch to the graph of the longer cache), wall ms each; a replayed step is ms_per_step",
                 "note": "the trigger step: decode from the graph, then every layer's 256 oldest window tokens pruned + compressed into an extent of its cache (storage prepared 8 steps ahead: no allocation in the step); the graph of the steps behind it is recorded 8 steps ahead, between replays"}
         w.extra.pop("trigger_step_ms", None)

@@ -31,7 +31,7 @@ a small arena of their own, an EXTENT, and lists its view in a device table next
 already compressed is read, written or moved; the pair form of the one-pass decode launch takes the blocks behind the base tokens
 from the table (mustafar_decode_attention_extents), so the base pointers, the table pointer and therefore a graph captured ahead
 stay valid across the trigger.  `tokens` / the four arrays keep describing the BASE; `total_tokens` counts the extents too,
-`to_reference()` concatenates, and after `MAX_EXTENTS` triggers (or when a launch form that cannot read extents is asked for)
+`to_reference()` concatenates, and after `MAX_EXTENTS` triggers (512: 128 k generated tokens) or when a launch form that cannot read extents is asked for
 `consolidate()` re-houses everything into one base again.
 """
 from __future__ import annotations
@@ -117,7 +117,8 @@ def _head_index(heads: int, device) -> torch.Tensor:
 
 class CompressedArena:
     TILES_PER_TOKEN = 2   # head_dim 128 / 64
-    MAX_EXTENTS = 64      # appended 256-token extents listed in the device table (16 k tokens of generation) before a consolidation
+    MAX_EXTENTS = 512     # appended 256-token extents listed in the device table before a consolidation: 128 k tokens of generation, i.e. every
+                          # length the one-pass launch serves (round 3: 64 -- a 170-ms copy of the cache every 16 k tokens at c3; the table is 28 KB)
     VIEW_BYTES = ctypes.sizeof(_lib.CacheView)
 
     def __init__(self, heads: int, which: str, device, cap_tokens: int, nz_cap: int, slack: float = DEFAULT_SLACK,
