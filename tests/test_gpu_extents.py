@@ -73,8 +73,10 @@ def test_extents_equal_in_place_append_and_dense_through_three_triggers(engine, 
     V_all = torch.cat([V0] + vs, 2)
     want = _dense(qs[-1], K_all, V_all, 1280, 0.7, hq // hkv)
     torch.testing.assert_close(o_ext[-1].float(), want, rtol=4e-3, atol=2e-3)
-    # the extents cost what they hold: a few per cent over the bytes in use, nothing re-housed
-    assert p_ext[0].bytes_reserved() <= p_ext[0].bytes_in_use() * 1.06 + 4096 * p_ext[0].heads
+    # the extents cost what they hold: a few per cent over the bytes in use, nothing re-housed (+ the device table of their views:
+    # 512 entries x 56 bytes, a constant that does not grow with the cache)
+    table = p_ext[0].MAX_EXTENTS * p_ext[0].VIEW_BYTES
+    assert p_ext[0].bytes_reserved() <= p_ext[0].bytes_in_use() * 1.06 + 4096 * p_ext[0].heads + table
 
 
 def test_addresses_survive_a_trigger_and_a_graph_captured_ahead_replays_behind_it():
