@@ -33,6 +33,7 @@ CASES = {  # BASELINE.json configs[1..4]: (Hq, Hkv, sparsity, L, batch)
     "c3": (32, 8, 0.7, 8192, 8),
     "c4": (32, 8, 0.8, 32768, 4),
     "c5": (32, 8, 0.7, 16384, 16),
+    "g2": (32, 16, 0.7, 4096, 4),      # GQA-2 at size: the G = 2 instantiation of the pair kernel (round 4)
     "s4": (32, 8, 0.7, 4096, 8),
     "s32": (32, 8, 0.7, 32768, 8),
 }
@@ -101,7 +102,7 @@ def _new(batch, Hq, Hkv):
             torch.randn(batch, Hkv, 1, 128, device=DEV).half())
 
 
-@pytest.mark.parametrize("name,structure", [("c2", 2), ("c3", 2), ("c4", 2), ("c5", 2), ("s4", 2), ("s32", 2), ("c3", 0), ("c5", 1)])
+@pytest.mark.parametrize("name,structure", [("c2", 2), ("c3", 2), ("c4", 2), ("c5", 2), ("s4", 2), ("s32", 2), ("g2", 2), ("c3", 0), ("c5", 1)])
 def test_fused_arena_eager_and_graph_at_bench_shape(name, structure):
     """structure 2 = the library's own choice by size (the one-pass launch at every config since round 3); the two-launch
     structure is forced once at c3, the one-pass launch named explicitly once at c5."""

@@ -79,7 +79,7 @@ def test_from_reference_round_trip_and_hook_append_equivalence():
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
 
 
-@pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4)])
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4), (8, 4)])
 def test_decode_through_arena_is_bit_identical(hq, hkv):
     """Same prompt, same steps, across a 256-token trigger: arena cache vs contiguous cache, fused entry point."""
     from mustafar_amd.hook import MustafarAttention, MustafarConfig

@@ -27,7 +27,7 @@ def _dense_reference(q, K_all, V_all, C, ks, vs, groups):
 
 
 @pytest.mark.parametrize("api", ["reference", "native", "fused"])
-@pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4)])
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4), (8, 4)])
 def test_prefill_then_decode_matches_dense(api, hq, hkv):
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
     torch.manual_seed(42)

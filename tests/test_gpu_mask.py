@@ -46,7 +46,7 @@ def structure(request):
 
 @pytest.mark.parametrize("structure", [0, 1], indirect=True)
 @pytest.mark.parametrize("arena", [False, True])
-@pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4)])
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (4, 4), (8, 4)])
 def test_fused_decode_with_left_padding_mask(arena, hq, hkv, structure):
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
     torch.manual_seed(3)
