@@ -1,4 +1,9 @@
-"""scratch: c3 leg through two triggers: kernel durations of the extents instantiation at T + 256, T + 512"""
+#!/usr/bin/env python3
+"""A decode leg of `steps` graph-replayed steps through its 256-token triggers (bench.py's timed_graph): tokens/s incl. the triggers, the
+one-pass kernel's duration at the END of the leg (the extents instantiation, at T + 256 x triggers) and every trigger step's wall time.
+
+    python tools/bench_trigger_leg.py [c3] [300]
+"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
