@@ -514,6 +514,20 @@ def run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib):
            "kernel": rl["kernel"], "kernel_us": rl["avg_launch_us"], "roofline_frac": rl["frac"], "roofline_achieved_GBps": rl["achieved"],
            "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"], "traffic": rl["traffic"], "kv_bytes_reference_layout": int(w.ref_kv_bytes), "dense_kv_bytes": int(w.dense_bytes),
            "arena_bytes_in_use": w.extra.get("arena_bytes_in_use"), "arena_bytes_reserved": w.extra.get("arena_bytes_reserved")}
+    if (w.Hq // w.Hkv) % 4 != 0:
+        # MHA / GQA-2 (c2): >= 256 consecutive steps through the 256-token trigger -- extents and a device-side T exist for every group
+        # count since round 4, so the graph recorded ahead (or the SAME graph) goes on behind the trigger here as well
+        nst = 256
+        w.extra.pop("trigger_step_ms", None)
+        w.rehearse_trigger()
+        dt_t, _ = w.timed_graph(nst, 1)
+        trig = {"value": round(world * w.batch * nst / dt_t, 2), "unit": "tokens/s", "steps": nst, "ms_per_step": round(dt_t / nst * 1e3, 4),
+                "triggers": w.extra.get("triggers_in_timed_region"), "trigger_step_ms": w.extra.get("trigger_step_ms")}
+        w.extra.pop("trigger_step_ms", None)
+        dt_1, _ = w.timed_graph(nst, 1, device_t=True)
+        trig["one_graph_device_side_T"] = {"value": round(world * w.batch * nst / dt_1, 2), "ms_per_step": round(dt_1 / nst * 1e3, 4),
+                                           "triggers": w.extra.get("triggers_in_timed_region"), "trigger_step_ms": w.extra.get("trigger_step_ms")}
+        out["tokens_per_sec_incl_trigger"] = trig
     if (w.Hq // w.Hkv) % 4 == 0:   # the same leg on the other two engines (GQA-4 kernels only), chosen per instance (cfg.engine -> flags)
         for eng, key in (("valu", "fma_engine_fma_mix"), ("mfma", "fma_engine_mfma")):
             w.cfg.engine = eng
