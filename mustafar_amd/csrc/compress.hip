@@ -407,20 +407,27 @@ __device__ __forceinline__ uint64_t gran_load(const uint64_t* g) { return __hip_
 
 // K geometry: registers J .. 63 of the block.  f = keep flags of register J (bit 0 / bit 16), raw = its two halfs.
 // `run` = stream position (half2 units, inside the block) of the next tile: wave-uniform.
+// keep flags of a word (two halfs): bit 0 / bit 16 set iff the half is kept (magnitude >= thr) and non-zero (-0.0 is zero)
+__device__ __forceinline__ uint32_t keep_flags(uint32_t raw, uint32_t tt)
+{
+    const uint32_t keep = ((raw | 0x80008000u) - tt) >> 15;                 // the guard bit of a half survives iff its magnitude >= thr
+    const uint32_t nzf = ((raw & 0x7fff7fffu) + 0x7fff7fffu) >> 15;
+    return keep & nzf & 0x00010001u;
+}
+// K geometry, first pass over registers J .. 63 of the block: masks, starts and the block's length, nothing written to LDS.
+// f = keep flags of the registers (bit 0 / bit 16).  `run` = stream position (half2 units, inside the block) of the next tile:
+// wave-uniform.  half_run: `run` in front of tile 64 (where the second half of the block's image begins).
 template <int J>
-__device__ __forceinline__ void key_pack(const uint32_t (&f)[kD / 2], const uint32_t (&raw)[kD / 2], uint16_t* s_out, int lane, uint32_t& run,
-                                         uint32_t& a_lo, uint32_t& a_hi, uint32_t& b_lo, uint32_t& b_hi, uint32_t& sa, uint32_t& sb)
+__device__ __forceinline__ void key_count(const uint32_t (&f)[kD / 2], uint32_t& run, uint32_t& half_run, uint32_t& a_lo, uint32_t& a_hi,
+                                          uint32_t& b_lo, uint32_t& b_hi, uint32_t& sa, uint32_t& sb)
 {
     if constexpr (J < kD / 2) {
+        if constexpr (J == kD / 4) half_run = run;
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const bool kept = half ? (f[J] >> 16) != 0 : (f[J] & 1u) != 0;
             const uint64_t m = __ballot(kept);                       // bit l <=> token l of the block has element 2J + half
-            const int cnt = __popcll(m), padded = (cnt + 7) & ~7;
-            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            uint16_t* tile = s_out + 2 * run;
-            if (kept) tile[rank] = (uint16_t)(half ? raw[J] >> 16 : raw[J]);
-            if (lane >= cnt && lane < padded) tile[lane] = 0;         // compression.py:309 relies on a pre-zeroed buffer
+            const int padded = (__popcll(m) + 7) & ~7;
             const uint64_t mr = __builtin_bitreverse64(m);            // as stored: MSB = element 0
             constexpr int D = 2 * J;
             if (half == 0) {
@@ -432,15 +439,49 @@ __device__ __forceinline__ void key_pack(const uint32_t (&f)[kD / 2], const uint
             }
             run += padded >> 1;
         }
-        key_pack<J + 1>(f, raw, s_out, lane, run, a_lo, a_hi, b_lo, b_hi, sa, sb);
+        key_count<J + 1>(f, run, half_run, a_lo, a_hi, b_lo, b_hi, sa, sb);
+    }
+}
+// Second pass over registers J .. JE - 1: the lane's own element goes to rank(lane) of its tile in the LDS image of this HALF of
+// the block's stream (s_img, 8 KB: 64 tiles of at most 64 halfs); `run` restarts at 0 with the half.
+template <int J, int JE>
+__device__ __forceinline__ void key_fill(const uint32_t (&f)[kD / 2], const uint32_t (&raw)[kD / 2], uint16_t* s_img, int lane, uint32_t& run)
+{
+    if constexpr (J < JE) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const bool kept = half ? (f[J] >> 16) != 0 : (f[J] & 1u) != 0;
+            const uint64_t m = __ballot(kept);
+            const int cnt = __popcll(m), padded = (cnt + 7) & ~7;
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            uint16_t* tile = s_img + 2 * run;
+            if (kept) tile[rank] = (uint16_t)(half ? raw[J] >> 16 : raw[J]);
+            if (lane >= cnt && lane < padded) tile[lane] = 0;         // compression.py:309 relies on a pre-zeroed buffer
+            run += padded >> 1;
+        }
+        key_fill<J + 1, JE>(f, raw, s_img, lane, run);
     }
 }
 
 // grid: x = token block, y = head, z = side; ONE wave.  gran: [sides][B'][ntb] words, zero at launch.  overflow: bit 0 = a
 // head outgrew its region (nothing of the offending blocks is written; the caller re-houses and repeats), bit 1 = a poll ran out.
-__global__ __launch_bounds__(64, 2) void compress_block_kernel(Side s0, Side s1, int ntb, uint64_t* __restrict__ gran, int32_t* __restrict__ overflow)
+// grid: x = token block, y = head, z = side; ONE wave.  gran: [sides][B'][ntb] words, zero at launch.  overflow: bit 0 = a
+// head outgrew its region (nothing of the offending blocks is written; the caller re-houses and repeats), bit 1 = a poll ran out.
+// Round 4b: the block's stream leaves in TWO halves (tiles 0..63, tiles 64..127) through an 8 KB LDS image instead of one of 16 KB
+// (the lengths are counted before anything is packed), and the kernel is compiled for three waves per SIMD: 12 waves per CU
+// instead of 8 cover for each other's loads, polls and stores.
+#ifndef MUSTAFAR_CB_WAVES
+#define MUSTAFAR_CB_WAVES 3
+#endif
+__device__ __forceinline__ void flush_image(const uint16_t* s_img, uint16_t* dst_halfs, uint32_t n_half2, int lane)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_out[64 * kD];   // the block's stream, worst case (nothing pruned)
+    uint4* dst = reinterpret_cast<uint4*>(dst_halfs);
+    const int n16 = (int)(n_half2 >> 2);   // every tile is padded to 8 halfs = 16 bytes
+    for (int p = lane; p < n16; p += 64) dst[p] = reinterpret_cast<const uint4*>(s_img)[p];
+}
+__global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(Side s0, Side s1, int ntb, uint64_t* __restrict__ gran, int32_t* __restrict__ overflow)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_img[64 * 64];   // one half of the block's stream, worst case (nothing pruned)
     const bool z = blockIdx.z != 0;
     const uint16_t* x = z ? s1.x : s0.x;
     const int64_t head_stride = z ? s1.head_stride : s0.head_stride;
@@ -454,10 +495,9 @@ __global__ __launch_bounds__(64, 2) void compress_block_kernel(Side s0, Side s1,
     const int kth = z ? s1.kth : s0.kth;
     const int key = z ? s1.key : s0.key;
     const int lane = threadIdx.x, tb = blockIdx.x, h = blockIdx.y;
-    const uint32_t H = 0x80008000u, ONES = 0x00010001u;
 
     const uint4* src = reinterpret_cast<const uint4*>(x + h * head_stride + ((int64_t)tb * 64 + lane) * kD);
-    uint32_t raw[kD / 2], w[kD / 2];
+    uint32_t raw[kD / 2];
 #pragma unroll
     for (int p = 0; p < kD / 8; p++) {
         const uint4 v = src[p];
@@ -466,27 +506,29 @@ __global__ __launch_bounds__(64, 2) void compress_block_kernel(Side s0, Side s1,
     // k-th smallest magnitude of the lane's row, sliced by bit (select_kth.h: ~1 300 operations against the 3 840 of the
     // search by value in tile_meta_kernel); 0 keeps everything (rows already pruned)
     const uint32_t thr = kth > 0 ? kth_magnitude128(raw, kth) : 0u;
-    const uint32_t tt = thr | (thr << 16);
-#pragma unroll
-    for (int j = 0; j < kD / 2; j++) {   // w[j]: bit 0 / bit 16 set iff element 2j / 2j + 1 is kept and non-zero (-0.0 is zero)
-        const uint32_t keep = ((raw[j] | H) - tt) >> 15;                 // the guard bit of a half survives iff its magnitude >= thr
-        const uint32_t nzf = ((raw[j] & 0x7fff7fffu) + 0x7fff7fffu) >> 15;
-        w[j] = keep & nzf & ONES;
-    }
+    uint32_t tt = thr | (thr << 16);
     uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;   // masks of tiles lane and 64 + lane (MSB = element 0)
     uint32_t sa = 0, sb = 0;                            // their starts inside the block, half2 units
-    uint32_t total = 0;                                 // the block's length, half2 units (wave-uniform)
+    uint32_t total = 0, total_a = 0;                    // the block's length / the length of its first 64 tiles, half2 units (wave-uniform)
+    int na = 0, nb = 0;
+    uint32_t w[kD / 2];                                 // K: the keep flags of every word (V recomputes them where it needs them:
+                                                        // the V path would otherwise hold 64 more registers than the K path)
+    // ---- lengths first: nothing is packed before the block's length is published
     if (key) {
-        key_pack<0>(w, raw, s_out, lane, total, a_lo, a_hi, b_lo, b_hi, sa, sb);
+#pragma unroll
+        for (int j = 0; j < kD / 2; j++) w[j] = keep_flags(raw[j], tt);
+        key_count<0>(w, total, total_a, a_lo, a_hi, b_lo, b_hi, sa, sb);
     } else {
 #pragma unroll
         for (int j = 0; j < kD / 2; j++) {
-            const uint32_t two = ((w[j] << 1) | (w[j] >> 16)) & 3u;   // (element 2j, element 2j + 1)
+            const uint32_t wj = keep_flags(raw[j], tt);
+            const uint32_t two = ((wj << 1) | (wj >> 16)) & 3u;   // (element 2j, element 2j + 1)
             const int e = 2 * (j & 31);
             uint32_t& word = (j < 32) ? (e < 32 ? a_hi : a_lo) : (e < 32 ? b_hi : b_lo);
             word |= two << (30 - (e & 31));
         }
-        const int na = __popc(a_lo) + __popc(a_hi), nb = __popc(b_lo) + __popc(b_hi);
+        na = __popc(a_lo) + __popc(a_hi);
+        nb = __popc(b_lo) + __popc(b_hi);
         const int32_t pa = ((na + 7) & ~7) >> 1, pb = ((nb + 7) & ~7) >> 1;   // compression.py:46-48
         int32_t ca = pa, cb = pb;
 #pragma unroll
@@ -494,30 +536,35 @@ __global__ __launch_bounds__(64, 2) void compress_block_kernel(Side s0, Side s1,
             const int32_t ua = __shfl_up(ca, o), ub = __shfl_up(cb, o);
             if (lane >= o) { ca += ua; cb += ub; }
         }
-        const int32_t tot_a = __shfl(ca, 63);
-        total = (uint32_t)(tot_a + __shfl(cb, 63));
+        total_a = (uint32_t)__shfl(ca, 63);
+        total = total_a + (uint32_t)__shfl(cb, 63);
         sa = (uint32_t)(ca - pa);
-        sb = (uint32_t)(tot_a + cb - pb);
-        // the lane appends the kept values of its two tiles in element order, then the zeros up to the padded lengths
-        uint32_t cur = 2 * sa;   // halfs
-#pragma unroll
-        for (int j = 0; j < kD / 2; j++) {
-            if (j == 32) {
-#pragma unroll
-                for (int i = 0; i < 7; i++) if (na + i < 2 * pa) s_out[cur + i] = 0;
-                cur = 2 * sb;
-            }
-            if (w[j] & 1u) s_out[cur] = (uint16_t)raw[j];
-            cur += w[j] & 1u;
-            if (w[j] >> 16) s_out[cur] = (uint16_t)(raw[j] >> 16);
-            cur += w[j] >> 16;
-        }
-#pragma unroll
-        for (int i = 0; i < 7; i++) if (nb + i < 2 * pb) s_out[cur + i] = 0;
+        sb = total_a + (uint32_t)(cb - pb);
     }
-    // ---- publish the block's length, then collect the lengths in front of it
+    // ---- publish the block's length
     uint64_t* g = gran + ((int64_t)(z ? gridDim.y : 0) + h) * ntb;
     if (lane == 0) gran_publish(g + tb, total);
+    // ---- first half of the image (tiles 0..63) while the blocks in front finish counting
+    if (key) {
+        uint32_t run = 0;
+        key_fill<0, kD / 4>(w, raw, s_img, lane, run);
+    } else {
+        // the lane appends the kept values of its first tile in element order, then the zeros up to the padded length
+        asm volatile("" : "+v"(tt));   // (the flags are recomputed, not kept from the counting loop above)
+        uint32_t cur = 2 * sa;         // halfs
+#pragma unroll
+        for (int j = 0; j < kD / 4; j++) {
+            const uint32_t wj = keep_flags(raw[j], tt);
+            if (wj & 1u) s_img[cur] = (uint16_t)raw[j];
+            cur += wj & 1u;
+            if (wj >> 16) s_img[cur] = (uint16_t)(raw[j] >> 16);
+            cur += wj >> 16;
+        }
+        const int pa2 = (na + 7) & ~7;
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (na + i < pa2) s_img[cur + i] = 0;
+    }
+    // ---- collect the lengths in front of the block
     int32_t* head_acc = accum + (int64_t)h * rows.idx_stride + rows.tile0;
     uint32_t sum = 0;
     bool failed = false;
@@ -554,9 +601,28 @@ __global__ __launch_bounds__(64, 2) void compress_block_kernel(Side s0, Side s1,
         if (lane == 0 && overflow) atomicOr(overflow, 1);
         return;
     }
-    uint4* dst = reinterpret_cast<uint4*>(nz + 8 * (int64_t)nz_offset[h] + 2 * (int64_t)base);
-    const int n16 = (int)(total >> 2);   // every tile is padded to 8 halfs = 16 bytes
-    for (int p = lane; p < n16; p += 64) dst[p] = reinterpret_cast<const uint4*>(s_out)[p];
+    uint16_t* dst = nz + 8 * (int64_t)nz_offset[h] + 2 * (int64_t)base;
+    flush_image(s_img, dst, total_a, lane);
+    // ---- second half (tiles 64..127): the same 8 KB (LDS operations of a wave execute in order: the reads of the flush are done)
+    if (key) {
+        uint32_t run = 0;
+        key_fill<kD / 4, kD / 2>(w, raw, s_img, lane, run);
+    } else {
+        asm volatile("" : "+v"(tt));
+        uint32_t cur = 2 * (sb - total_a);
+#pragma unroll
+        for (int j = kD / 4; j < kD / 2; j++) {
+            const uint32_t wj = keep_flags(raw[j], tt);
+            if (wj & 1u) s_img[cur] = (uint16_t)raw[j];
+            cur += wj & 1u;
+            if (wj >> 16) s_img[cur] = (uint16_t)(raw[j] >> 16);
+            cur += wj >> 16;
+        }
+        const int pb2 = (nb + 7) & ~7;
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (nb + i < pb2) s_img[cur + i] = 0;
+    }
+    flush_image(s_img, dst + 2 * (int64_t)total_a, total - total_a, lane);
 }
 
 // Move the rows [drop, len) of every head's window to the front (model :392-393 slices and clones; here in place).

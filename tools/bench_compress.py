@@ -19,7 +19,7 @@ for name in sys.argv[1:] or ["c3", "c4"]:
     tiles = T * 2
     st = torch.cuda.current_stream().cuda_stream
     res = dict(cfg=name, rows=Bp * T, prune_us=round(t_prune * 1e6, 1), prune_GBps=round(2 * x.numel() * 2 / t_prune / 1e9, 1))
-    for which in ("key", "value"):
+    for which in () if os.environ.get("FUSED_ONLY") else ("key", "value"):
         bmp = torch.empty((Bp, tiles), dtype=torch.int64, device=dev)
         acc = torch.empty((Bp, tiles + 1), dtype=torch.int32, device=dev)
         ho = torch.empty((Bp + 1,), dtype=torch.int64, device=dev)

@@ -120,6 +120,26 @@ def main():
             edges = np.linspace(0, span, 11)
             occ = [(np.minimum(t[:, 6], edges[i + 1]) - np.maximum(t[:, 0], edges[i])).clip(min=0).sum() / (edges[i + 1] - edges[i]) / 1024 for i in range(10)]
             print("     waves/SIMD per tenth of the span: " + " ".join(f"{o:5.2f}" for o in occ))
+            if k == 7:
+                # dispatch order: workgroups are handed out by linear id; how do start / end / life depend on it?
+                gp = r[:, 9]
+                gx = (gp & np.uint64(0xffffff)).astype(np.int64)
+                wg = ((gp >> np.uint64(24)) & np.uint64(0xffffff)).astype(np.int64) * (gx.max() + 1) + gx
+                nb = 8
+                order = np.argsort(wg, kind="stable")
+                for name2, col in (("start", t[:, 0]), ("end", t[:, 6]), ("life", life)):
+                    parts = np.array_split(col[order], nb)
+                    print(f"     {name2:5s} by workgroup id, eighths (p50): " + " ".join(f"{np.median(x):6.2f}" for x in parts))
+                # age rank of a wave on its SIMD (by start time) against its end
+                simd = cu * 4 + ((hw >> np.uint64(4)) & np.uint64(3)).astype(np.int64)
+                ranks = np.zeros(len(r), dtype=np.int64)
+                for s_ in np.unique(simd):
+                    ix = np.nonzero(simd == s_)[0]
+                    ranks[ix[np.argsort(t[ix, 0], kind="stable")]] = np.arange(len(ix))
+                print("     end by age rank on the SIMD (p50): " + " ".join(f"{np.median(t[ranks == q, 6]):6.2f}" for q in range(int(ranks.max()) + 1)))
+                print("     life by age rank on the SIMD (p50): " + " ".join(f"{np.median(life[ranks == q]):6.2f}" for q in range(int(ranks.max()) + 1)))
+        if os.environ.get("MUSTAFAR_TRACE_DUMP"):
+            np.save(os.environ["MUSTAFAR_TRACE_DUMP"] + f"_{a.cfg}_{parts[0]}.npy", rec)
 
 
 if __name__ == "__main__":
