@@ -385,18 +385,19 @@ __global__ __launch_bounds__(kThreads) void tile_pack_kernel(Side s0, Side s1, i
 // above are bound by vector instructions, not bytes (pass 1 ~5 800 per block, pass 2 ~3 200: 136 us per side at c3 against
 // 40 us of traffic), and pass 2 re-derives from memory what pass 1 had in registers.  Here one wave keeps the 64 raw rows
 // in registers from the load to the packed stream:
-//   threshold   lane = row, sliced by bit (select_kth.h): the 64 words of the row are transposed into bit planes and the
-//               k-th smallest magnitude is read off 128-bit candidate sets; 16 KB of LDS per wave leave two to three
-//               waves per SIMD, so the extra registers cost nothing
-//   K           tile d = element d of the 64 rows: one ballot; the lane's own element goes to rank(lane) of the tile in an
-//               LDS image of the block's stream, the mask and the tile's start to lane d % 64 (v_writelane)
-//   V           tiles = the lane's own row halves: the lane walks its 128 flags and appends the kept values itself
+//   threshold   lane = row, sliced by bit (select_kth.h): the bytes of the row are transposed into bit planes and the
+//               k-th smallest magnitude is read off 128-bit candidate sets
+//   K           tile d = element d of the 64 rows: one ballot; first pass: the mask and the tile's start go to lane d % 64
+//               (v_writelane) and the lengths add up; second pass, half a block at a time: the lane's own element goes to
+//               rank(lane) of the tile in an LDS image of that half of the block's stream
+//   V           tiles = the lane's own row halves: the lane packs its 128 flags into masks, a scan over the lanes gives the
+//               starts; then it walks its flags again and appends the kept values itself, first half-row, then second
 //   base        the stream position of the block = sum of the lengths of the blocks in front of it in the head.  Every
 //               block publishes its length as soon as it is known -- one 8-byte {length, valid} word, one sc1 store -- and
 //               reads the words of its predecessors (sc1 loads, polled).  Nobody waits before publishing, so the chain is one
 //               hop long whatever the number of blocks; workgroups are dispatched in linear order and a predecessor has a
 //               smaller linear id, so what a block waits for is running or done.  The poll is bounded all the same.
-//   flush       the LDS image (one contiguous range of the output) leaves as 16-byte stores
+//   flush       each half of the LDS image (one contiguous range of the output) leaves as 16-byte stores
 constexpr int kSpinMax = 1 << 22;
 
 __device__ __forceinline__ void gran_publish(uint64_t* g, uint32_t len)
@@ -405,8 +406,6 @@ __device__ __forceinline__ void gran_publish(uint64_t* g, uint32_t len)
 }
 __device__ __forceinline__ uint64_t gran_load(const uint64_t* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// K geometry: registers J .. 63 of the block.  f = keep flags of register J (bit 0 / bit 16), raw = its two halfs.
-// `run` = stream position (half2 units, inside the block) of the next tile: wave-uniform.
 // keep flags of a word (two halfs): bit 0 / bit 16 set iff the half is kept (magnitude >= thr) and non-zero (-0.0 is zero)
 __device__ __forceinline__ uint32_t keep_flags(uint32_t raw, uint32_t tt)
 {
@@ -415,17 +414,18 @@ __device__ __forceinline__ uint32_t keep_flags(uint32_t raw, uint32_t tt)
     return keep & nzf & 0x00010001u;
 }
 // K geometry, first pass over registers J .. 63 of the block: masks, starts and the block's length, nothing written to LDS.
-// f = keep flags of the registers (bit 0 / bit 16).  `run` = stream position (half2 units, inside the block) of the next tile:
+// tt = the row's threshold in both halfs (the keep flags are recomputed from it).  `run` = stream position (half2 units, inside the block) of the next tile:
 // wave-uniform.  half_run: `run` in front of tile 64 (where the second half of the block's image begins).
 template <int J>
-__device__ __forceinline__ void key_count(const uint32_t (&f)[kD / 2], uint32_t& run, uint32_t& half_run, uint32_t& a_lo, uint32_t& a_hi,
+__device__ __forceinline__ void key_count(const uint32_t tt, const uint32_t (&raw)[kD / 2], uint32_t& run, uint32_t& half_run, uint32_t& a_lo, uint32_t& a_hi,
                                           uint32_t& b_lo, uint32_t& b_hi, uint32_t& sa, uint32_t& sb)
 {
     if constexpr (J < kD / 2) {
         if constexpr (J == kD / 4) half_run = run;
+        const uint32_t fj = keep_flags(raw[J], tt);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            const bool kept = half ? (f[J] >> 16) != 0 : (f[J] & 1u) != 0;
+            const bool kept = half ? (fj >> 16) != 0 : (fj & 1u) != 0;
             const uint64_t m = __ballot(kept);                       // bit l <=> token l of the block has element 2J + half
             const int padded = (__popcll(m) + 7) & ~7;
             const uint64_t mr = __builtin_bitreverse64(m);            // as stored: MSB = element 0
@@ -439,18 +439,19 @@ __device__ __forceinline__ void key_count(const uint32_t (&f)[kD / 2], uint32_t&
             }
             run += padded >> 1;
         }
-        key_count<J + 1>(f, run, half_run, a_lo, a_hi, b_lo, b_hi, sa, sb);
+        key_count<J + 1>(tt, raw, run, half_run, a_lo, a_hi, b_lo, b_hi, sa, sb);
     }
 }
 // Second pass over registers J .. JE - 1: the lane's own element goes to rank(lane) of its tile in the LDS image of this HALF of
 // the block's stream (s_img, 8 KB: 64 tiles of at most 64 halfs); `run` restarts at 0 with the half.
 template <int J, int JE>
-__device__ __forceinline__ void key_fill(const uint32_t (&f)[kD / 2], const uint32_t (&raw)[kD / 2], uint16_t* s_img, int lane, uint32_t& run)
+__device__ __forceinline__ void key_fill(const uint32_t tt, const uint32_t (&raw)[kD / 2], uint16_t* s_img, int lane, uint32_t& run)
 {
     if constexpr (J < JE) {
+        const uint32_t fj = keep_flags(raw[J], tt);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            const bool kept = half ? (f[J] >> 16) != 0 : (f[J] & 1u) != 0;
+            const bool kept = half ? (fj >> 16) != 0 : (fj & 1u) != 0;
             const uint64_t m = __ballot(kept);
             const int cnt = __popcll(m), padded = (cnt + 7) & ~7;
             const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -459,19 +460,20 @@ __device__ __forceinline__ void key_fill(const uint32_t (&f)[kD / 2], const uint
             if (lane >= cnt && lane < padded) tile[lane] = 0;         // compression.py:309 relies on a pre-zeroed buffer
             run += padded >> 1;
         }
-        key_fill<J + 1, JE>(f, raw, s_img, lane, run);
+        key_fill<J + 1, JE>(tt, raw, s_img, lane, run);
     }
 }
 
 // grid: x = token block, y = head, z = side; ONE wave.  gran: [sides][B'][ntb] words, zero at launch.  overflow: bit 0 = a
 // head outgrew its region (nothing of the offending blocks is written; the caller re-houses and repeats), bit 1 = a poll ran out.
-// grid: x = token block, y = head, z = side; ONE wave.  gran: [sides][B'][ntb] words, zero at launch.  overflow: bit 0 = a
-// head outgrew its region (nothing of the offending blocks is written; the caller re-houses and repeats), bit 1 = a poll ran out.
-// Round 4b: the block's stream leaves in TWO halves (tiles 0..63, tiles 64..127) through an 8 KB LDS image instead of one of 16 KB
-// (the lengths are counted before anything is packed), and the kernel is compiled for three waves per SIMD: 12 waves per CU
-// instead of 8 cover for each other's loads, polls and stores.
+// Round 4b: four waves per SIMD instead of two (16 per CU cover for each other's loads, polls and stores: c3 158 -> 103 us) --
+//   * the block's stream leaves in TWO halves (tiles 0..63, tiles 64..127) through an 8 KB LDS image instead of one of 16 KB: the
+//     lengths are counted before anything is packed;
+//   * the keep flags are recomputed from the threshold wherever they are needed (6 operations per word) instead of kept in 64 registers;
+//   * the threshold search holds 32 plane words next to the row, not 64 (select_kth.h);
+//   125 vector registers, no spills (a build that reaches the register budget by spilling is 30 % SLOWER than the one it came from).
 #ifndef MUSTAFAR_CB_WAVES
-#define MUSTAFAR_CB_WAVES 3
+#define MUSTAFAR_CB_WAVES 4
 #endif
 __device__ __forceinline__ void flush_image(const uint16_t* s_img, uint16_t* dst_halfs, uint32_t n_half2, int lane)
 {
@@ -511,13 +513,11 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
     uint32_t sa = 0, sb = 0;                            // their starts inside the block, half2 units
     uint32_t total = 0, total_a = 0;                    // the block's length / the length of its first 64 tiles, half2 units (wave-uniform)
     int na = 0, nb = 0;
-    uint32_t w[kD / 2];                                 // K: the keep flags of every word (V recomputes them where it needs them:
+    uint32_t w[1];                                      // the flags are recomputed from tt wherever they are needed (V recomputes them where it needs them:
                                                         // the V path would otherwise hold 64 more registers than the K path)
     // ---- lengths first: nothing is packed before the block's length is published
     if (key) {
-#pragma unroll
-        for (int j = 0; j < kD / 2; j++) w[j] = keep_flags(raw[j], tt);
-        key_count<0>(w, total, total_a, a_lo, a_hi, b_lo, b_hi, sa, sb);
+        key_count<0>(tt, raw, total, total_a, a_lo, a_hi, b_lo, b_hi, sa, sb);
     } else {
 #pragma unroll
         for (int j = 0; j < kD / 2; j++) {
@@ -547,7 +547,8 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
     // ---- first half of the image (tiles 0..63) while the blocks in front finish counting
     if (key) {
         uint32_t run = 0;
-        key_fill<0, kD / 4>(w, raw, s_img, lane, run);
+        asm volatile("" : "+v"(tt));   // (the flags are recomputed, not kept from the pass above)
+        key_fill<0, kD / 4>(tt, raw, s_img, lane, run);
     } else {
         // the lane appends the kept values of its first tile in element order, then the zeros up to the padded length
         asm volatile("" : "+v"(tt));   // (the flags are recomputed, not kept from the counting loop above)
@@ -606,7 +607,8 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
     // ---- second half (tiles 64..127): the same 8 KB (LDS operations of a wave execute in order: the reads of the flush are done)
     if (key) {
         uint32_t run = 0;
-        key_fill<kD / 4, kD / 2>(w, raw, s_img, lane, run);
+        asm volatile("" : "+v"(tt));
+        key_fill<kD / 4, kD / 2>(tt, raw, s_img, lane, run);
     } else {
         asm volatile("" : "+v"(tt));
         uint32_t cur = 2 * (sb - total_a);

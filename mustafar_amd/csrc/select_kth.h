@@ -5,10 +5,10 @@
 // The search by value (thr |= bit iff fewer than k magnitudes are < thr | bit) costs a pass over the 64 registers per bit:
 // 15 x 64 x 4 = 3 840 operations per row-lane, two thirds of everything the compression kernel does.  Sliced by bit the same
 // search is 15 x ~21 operations on 128-bit sets:
-//   planes   the 64 words (two 16-bit magnitudes each) are transposed as two 32 x 32 bit matrices (5 butterfly stages each):
-//            word 31 - b of a transposed block = bit b of its 32 input words.  Plane k of the row = bit k of the low halfs and
-//            bit 16 + k of the high halfs = four 32-bit words.  (Which element sits at which bit of a plane does not matter:
-//            every plane uses the same order, and only counts and intersections are taken.)
+//   planes   the high bytes of the 128 magnitudes (four to a word: 32 words) and, later, the low bytes are transposed as 32 x 32 bit
+//            matrices (5 butterfly stages each): word 31 - b of a transposed block = bit b of its 32 input words.  Plane k of the
+//            row = bit k % 8 of the four byte positions = four 32-bit words.  (Which element sits at which bit of a plane does not
+//            matter: every plane uses the same order, and only counts and intersections are taken.)
 //   search   S = candidates (all), r = k.  From bit 14 down: Z = S \ plane (candidates whose bit is 0, the smaller ones);
 //            r <= |Z| ? the k-th smallest is among them, S = Z, the bit of the result is 0 : r -= |Z|, S = S & plane, bit = 1.
 // The result is the same value the search by value finds: the v with |{m < v}| < k <= |{m <= v}|.
@@ -38,21 +38,27 @@ MUSTAFAR_HD void bit_transpose32(uint32_t (&a)[32])
     }
 }
 
-// raw: the row as 64 words, element 2j in the low half of word j, element 2j + 1 in the high half (sign bits ignored).
-// Returns the k-th smallest magnitude (1 <= kth <= 128) as a 15-bit integer.
-MUSTAFAR_HD uint32_t kth_magnitude128(const uint32_t (&raw)[64], int kth)
+// The bytes 1 and 3 (HI) or 0 and 2 (!HI) of a and b: the high / low bytes of four consecutive magnitudes in one word.
+template <bool HI>
+MUSTAFAR_HD uint32_t gather_bytes(uint32_t a, uint32_t b)
 {
-    uint32_t a[32], b[32];
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(b, a, HI ? 0x07050301u : 0x06040200u);   // (selector 0..3: bytes of the second operand, 4..7: of the first)
+#else
+    const int sh = HI ? 8 : 0;
+    return ((a >> sh) & 0xffu) | (((a >> (16 + sh)) & 0xffu) << 8) | (((b >> sh) & 0xffu) << 16) | (((b >> (16 + sh)) & 0xffu) << 24);
+#endif
+}
+
+// One phase of the search: bits KHI .. KLO of the magnitudes (KHI - KLO < 8), whose planes are p[31 - 8 q - (k - KLO) ... ] for the
+// byte positions q = 0..3 of the gathered words.
+template <int KHI, int KLO, int SHIFT>
+MUSTAFAR_HD void kth_phase(const uint32_t (&p)[32], uint32_t& s0, uint32_t& s1, uint32_t& s2, uint32_t& s3, int& ns, int& r, uint32_t& thr)
+{
 #pragma unroll
-    for (int j = 0; j < 32; j++) { a[j] = raw[j]; b[j] = raw[32 + j]; }
-    bit_transpose32(a);
-    bit_transpose32(b);
-    uint32_t s0 = ~0u, s1 = ~0u, s2 = ~0u, s3 = ~0u;
-    int ns = 128, r = kth;
-    uint32_t thr = 0;
-#pragma unroll
-    for (int k = 14; k >= 0; k--) {
-        const uint32_t t0 = s0 & a[31 - k], t1 = s1 & a[15 - k], t2 = s2 & b[31 - k], t3 = s3 & b[15 - k];   // candidates with bit k set
+    for (int k = KHI; k >= KLO; k--) {
+        const int b = k - SHIFT;   // bit of the byte
+        const uint32_t t0 = s0 & p[31 - b], t1 = s1 & p[23 - b], t2 = s2 & p[15 - b], t3 = s3 & p[7 - b];   // candidates with bit k set
         const int nt = __builtin_popcount(t0) + __builtin_popcount(t1) + __builtin_popcount(t2) + __builtin_popcount(t3);
         const int nz = ns - nt;
         const bool low = r <= nz;   // the k-th smallest has bit k clear
@@ -64,6 +70,27 @@ MUSTAFAR_HD uint32_t kth_magnitude128(const uint32_t (&raw)[64], int kth)
         r = low ? r : r - nz;
         thr |= low ? 0u : (1u << k);
     }
+}
+
+// raw: the row as 64 words, element 2j in the low half of word j, element 2j + 1 in the high half (sign bits ignored).
+// Returns the k-th smallest magnitude (1 <= kth <= 128) as a 15-bit integer.
+// Round 4b: the planes are built in two rounds of ONE 32 x 32 transpose each -- the high bytes of the 128 magnitudes (bits 14..8), then,
+// when those planes are dead, the low bytes (bits 7..0) -- so that 32 words are live next to the row instead of 64: with it the
+// compression kernel fits four waves per SIMD.  Which element sits at which bit of a plane is the same in both rounds.
+MUSTAFAR_HD uint32_t kth_magnitude128(const uint32_t (&raw)[64], int kth)
+{
+    uint32_t p[32];
+    uint32_t s0 = ~0u, s1 = ~0u, s2 = ~0u, s3 = ~0u;
+    int ns = 128, r = kth;
+    uint32_t thr = 0;
+#pragma unroll
+    for (int j = 0; j < 32; j++) p[j] = gather_bytes<true>(raw[2 * j], raw[2 * j + 1]);
+    bit_transpose32(p);
+    kth_phase<14, 8, 8>(p, s0, s1, s2, s3, ns, r, thr);
+#pragma unroll
+    for (int j = 0; j < 32; j++) p[j] = gather_bytes<false>(raw[2 * j], raw[2 * j + 1]);
+    bit_transpose32(p);
+    kth_phase<7, 0, 0>(p, s0, s1, s2, s3, ns, r, thr);
     return thr;
 }
 #endif
