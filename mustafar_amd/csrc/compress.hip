@@ -31,55 +31,72 @@ __device__ __forceinline__ bool nonzero_h(uint16_t v) { return (v & 0x7fffu) != 
 // pruned entries become x * 0 = sign-preserving zero (:110).  fp16 magnitudes are monotone as unsigned integers for
 // non-NaN values, so thr is found bit by bit from the MSB: thr |= b  iff  fewer than k magnitudes are < (thr | b).
 //
-// Lane = row: one wave takes 64 rows, transposed through LDS (row stride 65 dwords: conflict-free both ways), and every
+// Lane = row: one wave takes 64 rows, transposed through LDS half a row at a time (row stride 33 dwords: conflict-free both ways), and every
 // lane finds the threshold of its own row held in 64 VGPRs (select_kth.h: bit planes + 128-bit candidate sets, ~1 300
 // operations per row-lane; round 1 searched by value, 15 steps x 64 words x 4 operations, and before that a wave per row
 // spent ~12 SALU + 4 VALU per step and per ROW on ballots and was instruction-bound at 1.7 TB/s).  Keep / prune is a SWAR
 // compare: with the guard bit H = 0x8000 set in each half, (m | H) - (thr | thr << 16) keeps H in a half iff that
 // magnitude >= thr (no borrow crosses the halves).
 constexpr int kPruneRows  = 64;            // rows per wave
-constexpr int kPruneLd    = kD / 2 + 1;    // LDS row stride in dwords
+constexpr int kPruneLd    = kD / 4 + 1;    // LDS row stride in dwords: HALF a row at a time (round 4b: 8.4 KB per wave instead of 16.6 KB,
+                                           // 16 waves per CU instead of 9 -- the kernel is a chain of load, transpose, search, transpose, store)
 
-__global__ __launch_bounds__(64) void prune_magnitude_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
-                                                             int64_t n_rows, int kth)
+__global__ __launch_bounds__(64, 4) void prune_magnitude_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
+                                                                int64_t n_rows, int kth)
 {
     __shared__ uint32_t s_rows[kPruneRows * kPruneLd];
     const int lane = threadIdx.x;
     const uint32_t H = 0x80008000u, ONES = 0x00010001u;
-    for (int64_t row0 = (int64_t)blockIdx.x * kPruneRows; row0 < n_rows; row0 += (int64_t)gridDim.x * kPruneRows) {
+    const int r0 = lane >> 3, c4 = lane & 7;   // a pass covers rows 8p .. 8p + 7: eight lanes x 16 B = one 128-byte half row each
+    {   // (one group of 64 rows per workgroup -- a grid-stride loop here makes the compiler hoist ~40 loop-invariant addresses and spill them)
+        const int64_t row0 = (int64_t)blockIdx.x * kPruneRows;
         const int rows = (int)((n_rows - row0) < kPruneRows ? (n_rows - row0) : kPruneRows);
-        // coalesced 16-byte loads: pass p covers rows 4p .. 4p+3 (16 lanes x 16 B per row)
         const uint4* src = reinterpret_cast<const uint4*>(x + row0 * (kD / 2));
-        __syncthreads();
-#pragma unroll 4
-        for (int p = 0; p < kPruneRows / 4; p++) {
-            const int r = p * 4 + (lane >> 4), c4 = lane & 15;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (r < rows) v = src[r * 16 + c4];
-            uint32_t* d = s_rows + r * kPruneLd + c4 * 4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-        __syncthreads();
-        uint32_t wh[kD / 2];   // magnitudes with the guard bits set (the signs stay behind in LDS)
+        uint32_t raw[kD / 2];   // the lane's row, signs included (the search does not read the sign planes)
 #pragma unroll
-        for (int j = 0; j < kD / 2; j++) wh[j] = s_rows[lane * kPruneLd + j] | H;
-        // k-th smallest magnitude, sliced by bit (select_kth.h; the guard bits sit where the planes are not read)
-        const uint32_t thr = kth_magnitude128(wh, kth);
+        for (int half = 0; half < 2; half++) {
+            uint4 v[kPruneRows / 8];
+            int piece = half * 8 + c4;
+            asm volatile("" : "+v"(piece));   // (keeps the second half's loads behind the first half's transpose: 32 registers in flight, not 64)
+#pragma unroll
+            for (int p = 0; p < kPruneRows / 8; p++) {
+                const int r = min(p * 8 + r0, rows - 1);   // (a short last group re-reads its last row: nothing of it is stored)
+                v[p] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + (uint32_t)(r * 16 + piece) * 16u);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < kPruneRows / 8; p++) {
+                uint32_t* d = s_rows + (p * 8 + r0) * kPruneLd + c4 * 4;
+                d[0] = v[p].x; d[1] = v[p].y; d[2] = v[p].z; d[3] = v[p].w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kD / 4; j++) raw[half * (kD / 4) + j] = s_rows[lane * kPruneLd + j];
+        }
+        // k-th smallest magnitude, sliced by bit (select_kth.h)
+        const uint32_t thr = kth_magnitude128<true>(raw, kth);
         // keep |x| >= thr, else the sign bit alone
         const uint32_t tt = thr | (thr << 16);
-#pragma unroll
-        for (int j = 0; j < kD / 2; j++) {
-            const uint32_t k = ((wh[j] - tt) >> 15) & ONES;   // 1 per half that stays
-            const uint32_t keep = (k << 16) - k;               // 0xffff per half that stays
-            s_rows[lane * kPruneLd + j] &= keep | H;
-        }
-        __syncthreads();
         uint4* dst = reinterpret_cast<uint4*>(out + row0 * (kD / 2));
-#pragma unroll 4
-        for (int p = 0; p < kPruneRows / 4; p++) {
-            const int r = p * 4 + (lane >> 4), c4 = lane & 15;
-            const uint32_t* d = s_rows + r * kPruneLd + c4 * 4;
-            if (r < rows) dst[r * 16 + c4] = make_uint4(d[0], d[1], d[2], d[3]);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kD / 4; j++) {
+                const uint32_t w = raw[half * (kD / 4) + j];
+                const uint32_t k = (((w | H) - tt) >> 15) & ONES;   // 1 per half that stays
+                const uint32_t keep = (k << 16) - k;                 // 0xffff per half that stays
+                s_rows[lane * kPruneLd + j] = w & (keep | H);
+            }
+            __syncthreads();
+            int piece = half * 8 + c4;
+            asm volatile("" : "+v"(piece));
+#pragma unroll
+            for (int p = 0; p < kPruneRows / 8; p++) {
+                const int r = p * 8 + r0;
+                const uint32_t* d = s_rows + r * kPruneLd + c4 * 4;
+                if (r < rows) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(dst) + (uint32_t)(r * 16 + piece) * 16u) = make_uint4(d[0], d[1], d[2], d[3]);
+            }
         }
     }
 }
@@ -809,7 +826,8 @@ int mustafar_prune_magnitude(void* stream, const void* x, void* out, int64_t n_r
     if (D != kD || kth < 1 || kth > D || n_rows < 0 || !x || !out) return MUSTAFAR_EINVAL;
     if (n_rows == 0) return 0;
     const int64_t blocks = (n_rows + kPruneRows - 1) / kPruneRows;
-    const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+    if (blocks > 0x7fffffff) return MUSTAFAR_EINVAL;
+    const unsigned grid = (unsigned)blocks;
     prune_magnitude_kernel<<<grid, 64, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const uint32_t*>(x), static_cast<uint32_t*>(out), n_rows, kth);
     return (int)hipGetLastError();

@@ -77,6 +77,9 @@ MUSTAFAR_HD void kth_phase(const uint32_t (&p)[32], uint32_t& s0, uint32_t& s1, 
 // Round 4b: the planes are built in two rounds of ONE 32 x 32 transpose each -- the high bytes of the 128 magnitudes (bits 14..8), then,
 // when those planes are dead, the low bytes (bits 7..0) -- so that 32 words are live next to the row instead of 64: with it the
 // compression kernel fits four waves per SIMD.  Which element sits at which bit of a plane is the same in both rounds.
+// SERIAL (device): a scheduling barrier between the rounds, for a caller that needs the second round's words NOT gathered while the
+// first round's planes are live (prune_magnitude_kernel fits 128 registers with it; compress_block_kernel is faster without).
+template <bool SERIAL = false>
 MUSTAFAR_HD uint32_t kth_magnitude128(const uint32_t (&raw)[64], int kth)
 {
     uint32_t p[32];
@@ -87,6 +90,9 @@ MUSTAFAR_HD uint32_t kth_magnitude128(const uint32_t (&raw)[64], int kth)
     for (int j = 0; j < 32; j++) p[j] = gather_bytes<true>(raw[2 * j], raw[2 * j + 1]);
     bit_transpose32(p);
     kth_phase<14, 8, 8>(p, s0, s1, s2, s3, ns, r, thr);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (SERIAL) __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int j = 0; j < 32; j++) p[j] = gather_bytes<false>(raw[2 * j], raw[2 * j + 1]);
     bit_transpose32(p);
