@@ -500,6 +500,49 @@ class Workload:
         return out
 
 
+def prefill_compression_leg(dev, lib, Hkv, s, T, batch):
+    """One layer's prefill compression at the workload's shape: prune + bitmaps + offsets + packed streams of K and V in ONE launch
+    (mustafar_cache_append_kv -> compress_block_kernel; kernel/compression.py:249-432 + the hook's prune, model :99-110), and the prune
+    kernel alone (what an unchanged hook calls first).  Bytes: the raw K and V read once, metadata and streams written once."""
+    from mustafar_amd import _lib, compression
+    from mustafar_amd.cache import CompressedArena
+    Bp = batch * Hkv
+    g = torch.Generator(device=dev).manual_seed(7)
+    xk = torch.randn((batch, Hkv, T, D), device=dev, generator=g).half()
+    xv = torch.randn((batch, Hkv, T, D), device=dev, generator=g).half()
+    kth = compression.kth_from_sparsity(s, D)
+    ka, va = CompressedArena.from_raw_pair(xk, xv, T, kth, kth)
+    scratch = torch.empty(int(lib.mustafar_compress_scratch_bytes(Bp, T)), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fused():
+        _lib.check(lib.mustafar_cache_append_kv(st, xk.data_ptr(), xv.data_ptr(), T * D, Bp, T, D, kth, kth, ka.view_ptr(), va.view_ptr(), 0,
+                                                ka._totals.data_ptr(), va._totals.data_ptr(), ka.nz_cap, va.nz_cap, ka._overflow.data_ptr(), scratch.data_ptr()), "append_kv")
+
+    def timed(fn, n=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n * 1e-3
+    t_f = timed(fused)
+    assert int(ka._overflow) == 0
+    out_k = torch.empty_like(xk)
+    t_p = timed(lambda: compression.prune_magnitude(xk.view(Bp, T, D), s, out=out_k.view(Bp, T, D)))
+    in_b = (xk.numel() + xv.numel()) * 2
+    out_b = int(ka.used.sum() + va.used.sum()) * 2 + 2 * Bp * (2 * T) * 12
+    return {"what": "one layer, K and V: prune + compress + pack in one launch (compress_block_kernel), the fused path's prefill; and the prune kernel alone (K)",
+            "us": round(t_f * 1e6, 1), "bytes_in": in_b, "bytes_out": out_b, "GBps": round((in_b + out_b) / t_f / 1e9, 1),
+            "frac_of_8TBps": round((in_b + out_b) / t_f / (HBM_PEAK_GBPS * 1e9), 3),
+            "prune_only_us": round(t_p * 1e6, 1), "prune_only_GBps": round(2 * xk.numel() * 2 / t_p / 1e9, 1),
+            "prune_only_frac_of_8TBps": round(2 * xk.numel() * 2 / t_p / (HBM_PEAK_GBPS * 1e9), 3)}
+
+
 def run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib):
     """c2 / c4 / c5 as sub-results of the same line: fused + graph, a few steps, kernel fractions, a self-check."""
     w = Workload(name, a.layers, dev, rank, world, dist, rehearse, timer, lib)
@@ -704,6 +747,11 @@ def main():
             if name != a.config:
                 sub[name] = run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib)
 
+    prefill = None
+    if world == 1 and not a.no_other_configs and a.api == "fused":
+        torch.cuda.empty_cache()
+        prefill = prefill_compression_leg(dev, lib, Hkv, s, T, batch)
+
     # ---- the metric's axis: Llama-3-8B geometry, 70 % / 70 %, batch 8 at L = 4k / 8k / 16k / 32k (N = 1) ------------------------
     sweep = None
     if world == 1 and not a.no_seq_sweep and a.api == "fused" and not a.no_graph and a.config == "c3":
@@ -758,7 +806,7 @@ def main():
         "allocator_note": "peak of the whole bench process: the reference-layout caches kept for the other call sequences and the self-check + "
                           "the appendable (arena) copy the timed fused leg runs on + transients",
         "roofline": roofline, "roofline_fma_mix": roofline_legs.get("valu"), "roofline_mfma": roofline_mfma, "cpu_baseline": cpu,
-        "other_call_sequences": others, "fma_engine_fma_mix": engine_legs.get("valu"), "fma_engine_mfma": engine_extra, "tokens_per_sec_incl_trigger": trig, "seq_sweep": sweep, "configs": sub,
+        "other_call_sequences": others, "fma_engine_fma_mix": engine_legs.get("valu"), "fma_engine_mfma": engine_extra, "tokens_per_sec_incl_trigger": trig, "prefill_compression": prefill, "seq_sweep": sweep, "configs": sub,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -310,6 +310,24 @@ def test_one_pass_compression_of_pruned_rows_and_small_shapes(B, H, t):
         assert torch.equal(torch.cat(a[2]).view(torch.int16), torch.cat(w[2]).view(torch.int16))
 
 
+@pytest.mark.parametrize("kth", [0, 1])
+def test_one_pass_compression_of_rows_without_a_single_zero(kth):
+    """Nothing to prune and no zero anywhere: every tile holds 64 values, so each half of a block's stream fills the kernel's 8 KB
+    image to the last byte (the image is sized for exactly this).  Equal to the two-call conversion of the same rows."""
+    from mustafar_amd.cache import CompressedArena
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X = (torch.rand((1, 3, 192, 128), generator=g) + 0.5) * (torch.randint(0, 2, (1, 3, 192, 128), generator=g) * 2 - 1)
+    X = X.half().cuda()
+    assert int((X == 0).sum()) == 0
+    ka, va = CompressedArena.from_raw_pair(X, X, 192, kth, kth)
+    for which, arena in (("key", ka), ("value", va)):
+        want = CompressedArena.from_pruned(X.reshape(3, 192, 128), which)
+        a, w = arena.to_reference(), want.to_reference()
+        assert torch.equal(a[0], w[0]) and torch.equal(a[1], w[1]) and torch.equal(a[3], w[3])
+        assert torch.equal(torch.cat(a[2]).view(torch.int16), torch.cat(w[2]).view(torch.int16))
+        assert int(torch.cat(a[2]).numel()) == 3 * 192 * 128   # nothing dropped, nothing padded
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_one_pass_compression_randomised_against_the_oracle(seed):
     """Random shapes, sparsities and value distributions (quantised values: many ties at the threshold; blocks of zeros; a few
