@@ -423,13 +423,13 @@ __device__ __forceinline__ void gran_publish(uint64_t* g, uint32_t len)
 }
 __device__ __forceinline__ uint64_t gran_load(const uint64_t* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// keep flags of a word (two halfs): bit 0 / bit 16 set iff the half is kept (magnitude >= thr) and non-zero (-0.0 is zero)
-__device__ __forceinline__ uint32_t keep_flags(uint32_t raw, uint32_t tt)
-{
-    const uint32_t keep = ((raw | 0x80008000u) - tt) >> 15;                 // the guard bit of a half survives iff its magnitude >= thr
-    const uint32_t nzf = ((raw & 0x7fff7fffu) + 0x7fff7fffu) >> 15;
-    return keep & nzf & 0x00010001u;
-}
+// Keep test of a word (two halfs), SWAR: with the guard bit H = 0x8000 set in each half, (m | H) - tt keeps H in a half iff that
+// magnitude >= the threshold (no borrow crosses the halves).  tt holds max(thr, 1) in both halfs: a kept element is one with
+// magnitude >= thr that is not zero (-0.0 is zero), and for thr >= 1 the first implies the second, for thr = 0 "magnitude >= 1" IS
+// the second -- two operations per word instead of eight.  Bit 15 / bit 31 of the result = element 2j / 2j + 1 is kept.
+__device__ __forceinline__ uint32_t keep_bits(uint32_t raw, uint32_t tt) { return (raw | 0x80008000u) - tt; }
+__device__ __forceinline__ bool kept_lo(uint32_t d) { return (d & 0x8000u) != 0; }
+__device__ __forceinline__ bool kept_hi(uint32_t d) { return (int32_t)d < 0; }
 // K geometry, first pass over registers J .. 63 of the block: masks, starts and the block's length, nothing written to LDS.
 // tt = the row's threshold in both halfs (the keep flags are recomputed from it).  `run` = stream position (half2 units, inside the block) of the next tile:
 // wave-uniform.  half_run: `run` in front of tile 64 (where the second half of the block's image begins).
@@ -439,10 +439,10 @@ __device__ __forceinline__ void key_count(const uint32_t tt, const uint32_t (&ra
 {
     if constexpr (J < kD / 2) {
         if constexpr (J == kD / 4) half_run = run;
-        const uint32_t fj = keep_flags(raw[J], tt);
+        const uint32_t fj = keep_bits(raw[J], tt);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            const bool kept = half ? (fj >> 16) != 0 : (fj & 1u) != 0;
+            const bool kept = half ? kept_hi(fj) : kept_lo(fj);
             const uint64_t m = __ballot(kept);                       // bit l <=> token l of the block has element 2J + half
             const int padded = (__popcll(m) + 7) & ~7;
             const uint64_t mr = __builtin_bitreverse64(m);            // as stored: MSB = element 0
@@ -465,10 +465,10 @@ template <int J, int JE>
 __device__ __forceinline__ void key_fill(const uint32_t tt, const uint32_t (&raw)[kD / 2], uint16_t* s_img, int lane, uint32_t& run)
 {
     if constexpr (J < JE) {
-        const uint32_t fj = keep_flags(raw[J], tt);
+        const uint32_t fj = keep_bits(raw[J], tt);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            const bool kept = half ? (fj >> 16) != 0 : (fj & 1u) != 0;
+            const bool kept = half ? kept_hi(fj) : kept_lo(fj);
             const uint64_t m = __ballot(kept);
             const int cnt = __popcll(m), padded = (cnt + 7) & ~7;
             const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -525,7 +525,8 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
     // k-th smallest magnitude of the lane's row, sliced by bit (select_kth.h: ~1 300 operations against the 3 840 of the
     // search by value in tile_meta_kernel); 0 keeps everything (rows already pruned)
     const uint32_t thr = kth > 0 ? kth_magnitude128(raw, kth) : 0u;
-    uint32_t tt = thr | (thr << 16);
+    const uint32_t thr1 = thr > 1u ? thr : 1u;          // (keep_bits: "kept" = magnitude >= thr and not zero)
+    uint32_t tt = thr1 | (thr1 << 16);
     uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;   // masks of tiles lane and 64 + lane (MSB = element 0)
     uint32_t sa = 0, sb = 0;                            // their starts inside the block, half2 units
     uint32_t total = 0, total_a = 0;                    // the block's length / the length of its first 64 tiles, half2 units (wave-uniform)
@@ -538,8 +539,8 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
     } else {
 #pragma unroll
         for (int j = 0; j < kD / 2; j++) {
-            const uint32_t wj = keep_flags(raw[j], tt);
-            const uint32_t two = ((wj << 1) | (wj >> 16)) & 3u;   // (element 2j, element 2j + 1)
+            const uint32_t wj = keep_bits(raw[j], tt);
+            const uint32_t two = ((wj >> 14) & 2u) | (wj >> 31);   // (element 2j, element 2j + 1)
             const int e = 2 * (j & 31);
             uint32_t& word = (j < 32) ? (e < 32 ? a_hi : a_lo) : (e < 32 ? b_hi : b_lo);
             word |= two << (30 - (e & 31));
@@ -572,11 +573,11 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
         uint32_t cur = 2 * sa;         // halfs
 #pragma unroll
         for (int j = 0; j < kD / 4; j++) {
-            const uint32_t wj = keep_flags(raw[j], tt);
-            if (wj & 1u) s_img[cur] = (uint16_t)raw[j];
-            cur += wj & 1u;
-            if (wj >> 16) s_img[cur] = (uint16_t)(raw[j] >> 16);
-            cur += wj >> 16;
+            const uint32_t wj = keep_bits(raw[j], tt);
+            if (kept_lo(wj)) s_img[cur] = (uint16_t)raw[j];
+            cur += (wj >> 15) & 1u;
+            if (kept_hi(wj)) s_img[cur] = (uint16_t)(raw[j] >> 16);
+            cur += wj >> 31;
         }
         const int pa2 = (na + 7) & ~7;
 #pragma unroll
@@ -631,11 +632,11 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
         uint32_t cur = 2 * (sb - total_a);
 #pragma unroll
         for (int j = kD / 4; j < kD / 2; j++) {
-            const uint32_t wj = keep_flags(raw[j], tt);
-            if (wj & 1u) s_img[cur] = (uint16_t)raw[j];
-            cur += wj & 1u;
-            if (wj >> 16) s_img[cur] = (uint16_t)(raw[j] >> 16);
-            cur += wj >> 16;
+            const uint32_t wj = keep_bits(raw[j], tt);
+            if (kept_lo(wj)) s_img[cur] = (uint16_t)raw[j];
+            cur += (wj >> 15) & 1u;
+            if (kept_hi(wj)) s_img[cur] = (uint16_t)(raw[j] >> 16);
+            cur += wj >> 31;
         }
         const int pb2 = (nb + 7) & ~7;
 #pragma unroll

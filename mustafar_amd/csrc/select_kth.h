@@ -26,8 +26,30 @@
 MUSTAFAR_HD void bit_transpose32(uint32_t (&a)[32])
 {
     uint32_t m = 0x0000ffffu;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the stages that move whole bytes (j = 16, j = 8) are one byte permute per word instead of shift + select:
+    //   j = 16: a' = (a & 0xffff0000) | (b >> 16),   b' = (b & 0x0000ffff) | (a << 16)
+    //   j = 8 : a' = (a & 0xff00ff00) | ((b >> 8) & 0x00ff00ff),   b' = (b & 0x00ff00ff) | ((a << 8) & 0xff00ff00)
+    // (v_perm_b32 D, S0, S1, sel: selector values 0..3 = bytes of S1, 4..7 = bytes of S0)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t x = a[k], y = a[k + 16];
+        a[k] = __builtin_amdgcn_perm(x, y, 0x07060302u);        // bytes: x3 x2 y3 y2
+        a[k + 16] = __builtin_amdgcn_perm(x, y, 0x05040100u);   // bytes: x1 x0 y1 y0
+    }
+#pragma unroll
+    for (int k = 0; k < 32; k = (k + 8 + 1) & ~8) {
+        const uint32_t x = a[k], y = a[k + 8];
+        a[k] = __builtin_amdgcn_perm(x, y, 0x07030501u);        // bytes: x3 y3 x1 y1
+        a[k + 8] = __builtin_amdgcn_perm(x, y, 0x06020400u);    // bytes: x2 y2 x0 y0
+    }
+    m = 0x0f0f0f0fu;
+#pragma unroll
+    for (int j = 4; j != 0; j >>= 1) {
+#else
 #pragma unroll
     for (int j = 16; j != 0; j >>= 1) {
+#endif
 #pragma unroll
         for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
             const uint32_t t = (a[k] ^ (a[k + j] >> j)) & m;
