@@ -124,6 +124,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Issue the global loads of one chunk into registers.  Buffer loads with num_records = chunk length:
 // lanes past the end get zeros from the range check and touch no memory, so there is no branch, no exec
 // masking and nothing is ever read beyond the packed stream.  `src` and `len` are wave-uniform.
+// SKIP: the upper half of the 4 KiB window is loaded (and, stage_commit, written to LDS) only for a chunk that reaches into it -- a
+// chunk is ~2 KiB at 70 % sparsity.  Used by the matrix-pipe engine of the lean kernels, whose steps also read their coefficients from
+// LDS (round 4b, kernel us c3 / c4 / c5: 32.5 / 57.1 / 110.0 -> 32.1 / 55.4 / 105.9).  NOT by the vector engines: nothing gained there
+// (they are bound by vector issue), and the wave-uniform branch makes the compiler move scalar registers around while the scalar loads
+// their asm statements issue are still in flight (wrong results; profiles/r04_probes.txt).
+template <bool SKIP = false>
 __device__ __forceinline__ Stage stage_issue(const unsigned char* __restrict__ src, uint32_t len, int lane)
 {
 #ifdef MUSTAFAR_PROBE_NOSTREAM   // timing-only build (tools/ab.py): zero records -> every stream load returns zeros without
@@ -146,19 +152,25 @@ __device__ __forceinline__ Stage stage_issue(const unsigned char* __restrict__ s
     // measured in round 2: the scalar branches cost the VALU engine 2-3 %, the matrix-pipe engine nothing either way)
     t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, MUSTAFAR_STREAM_AUX);        s.r0 = {t.x, t.y, t.z, t.w};
     t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024, 0, MUSTAFAR_STREAM_AUX); s.r1 = {t.x, t.y, t.z, t.w};
-    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048, 0, MUSTAFAR_STREAM_AUX); s.r2 = {t.x, t.y, t.z, t.w};
-    t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072, 0, MUSTAFAR_STREAM_AUX); s.r3 = {t.x, t.y, t.z, t.w};
+    if constexpr (SKIP) { s.r2 = {0u, 0u, 0u, 0u}; s.r3 = {0u, 0u, 0u, 0u}; }
+    if (!SKIP || len > 2048u) {
+        t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048, 0, MUSTAFAR_STREAM_AUX); s.r2 = {t.x, t.y, t.z, t.w};
+        t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072, 0, MUSTAFAR_STREAM_AUX); s.r3 = {t.x, t.y, t.z, t.w};
+    }
     return s;
 }
 
 // Copy the register image into the wave's LDS window (the zero tail is written too: the window is 4 KiB).
-__device__ __forceinline__ void stage_commit(unsigned char* lds, const Stage& s, int lane, uint32_t /*len*/)
+template <bool SKIP = false>
+__device__ __forceinline__ void stage_commit(unsigned char* lds, const Stage& s, int lane, uint32_t len)
 {
     uint4* w = reinterpret_cast<uint4*>(lds) + lane;
     w[0]   = s.r0;
     w[64]  = s.r1;
-    w[128] = s.r2;
-    w[192] = s.r3;
+    if (!SKIP || len > 2048u) {   // (a skipped upper half keeps a previous chunk's bytes: no gather of this chunk addresses them)
+        w[128] = s.r2;
+        w[192] = s.r3;
+    }
 }
 
 typedef h16 h16x2 __attribute__((ext_vector_type(2)));
@@ -2196,8 +2208,8 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
     }
     uint32_t i0 = bnd_get(bnd, CB);
     const uint32_t len0 = 4u * (bnd_get(bnd, CB + 1) - i0);
-    Stage st = stage_issue(nz_h + 4ull * i0, len0, lane);
-    stage_commit(lds, st, lane, len0);
+    Stage st = stage_issue<ENG == 1>(nz_h + 4ull * i0, len0, lane);
+    stage_commit<ENG == 1>(lds, st, lane, len0);
 #ifdef MUSTAFAR_WAVE_TRACE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
@@ -2208,7 +2220,7 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
         if (c < CB + CN - 1) {
             n0 = bnd_get(bnd, c + 1);
             nlen = 4u * (bnd_get(bnd, c + 2) - n0);
-            st = stage_issue(nz_h + 4ull * n0, nlen, lane);
+            st = stage_issue<ENG == 1>(nz_h + 4ull * n0, nlen, lane);
         }
         __builtin_amdgcn_wave_barrier();
 #ifdef MUSTAFAR_PROBE_HOTMETA
@@ -2229,7 +2241,7 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
         }
         __builtin_amdgcn_wave_barrier();
         if (c < CB + CN - 1) {
-            stage_commit(lds, st, lane, nlen);
+            stage_commit<ENG == 1>(lds, st, lane, nlen);
             i0 = n0;
         }
     }
