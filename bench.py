@@ -55,6 +55,8 @@ CONFIGS = {  # name: (label, Hq, Hkv, sparsity, L, batch)
 }
 CONFIGS["t8192"] = ("Llama-3-8B 70% T=8192 b8 [tools only]", 32, 8, 0.7, 8192 + 32, 8)
 CONFIGS["t8448"] = ("Llama-3-8B 70% T=8448 b8 [tools only]", 32, 8, 0.7, 8448 + 32, 8)
+CONFIGS["b1"] = ("Llama-3-8B 70% L=8192 b1 [tools only]", 32, 8, 0.7, 8192, 1)
+CONFIGS["b1l"] = ("Llama-3-8B 70% L=32768 b1 [tools only]", 32, 8, 0.7, 32768, 1)
 CONFIGS["m8"] = ("Llama-2-7B (MHA) 70% L=8192 b8 [tools only]", 32, 32, 0.7, 8192, 8)
 CONFIGS["g2"] = ("GQA-2 (32 q / 16 kv heads) 70% L=8192 b8 [tools only]", 32, 16, 0.7, 8192, 8)
 SEQ_SWEEP = ("s4", "c3", "s16", "s32")
