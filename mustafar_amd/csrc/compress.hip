@@ -531,8 +531,7 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
     uint32_t sa = 0, sb = 0;                            // their starts inside the block, half2 units
     uint32_t total = 0, total_a = 0;                    // the block's length / the length of its first 64 tiles, half2 units (wave-uniform)
     int na = 0, nb = 0;
-    uint32_t w[1];                                      // the flags are recomputed from tt wherever they are needed (V recomputes them where it needs them:
-                                                        // the V path would otherwise hold 64 more registers than the K path)
+    // (the keep bits of a word are recomputed from tt wherever they are needed: kept in registers they cost 64 of them)
     // ---- lengths first: nothing is packed before the block's length is published
     if (key) {
         key_count<0>(tt, raw, total, total_a, a_lo, a_hi, b_lo, b_hi, sa, sb);
