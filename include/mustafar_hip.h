@@ -157,8 +157,8 @@ typedef struct mustafar_cache_view {
  * [T_base + 256 i, T_base + 256 (i + 1)) in entry i of `k_extents` / `v_extents` -- arrays of mustafar_cache_view in DEVICE memory,
  * each describing a 256-token cache of its own (offsets relative to that extent; nz_head_stride != 0).  An entry is written once,
  * before the first call that names it, and never changed: a captured hipGraph of a call stays valid while the cache grows
- * behind it.  T_base and T - T_base are multiples of 256.  Read by the pair form of the one-pass launch (GQA groups % 4 == 0,
- * ld_scores % 32 == 0; mustafar_decode_reads_extents() tells); MUSTAFAR_EINVAL otherwise -- consolidate into one view then.
+ * behind it.  T_base and T - T_base are multiples of 256.  Read by the pair form of the one-pass launch (every group count: GQA-4 on the three engines,
+ * GQA-2 and MHA on v_fma_mix; ld_scores % 32 == 0; mustafar_decode_reads_extents() tells); MUSTAFAR_EINVAL otherwise -- consolidate into one view then.
  *   T_device   NULL: T is the number of compressed tokens.  Otherwise a device int holding the compressed tokens IN USE
  *              (T_base <= *T_device <= T, a multiple of 256 beyond T_base), and T is the CAPACITY the launch is sized for: grid,
  *              slabs, score scratch (ld_scores >= T + window capacity), mask columns.  The caller adds 256 to *T_device when a
@@ -238,7 +238,8 @@ int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int
  */
 int mustafar_cache_rehouse(void* stream, const mustafar_cache_view* src, const mustafar_cache_view* dst, int Bp, int tokens,
                            int64_t stream_halfs);
-/* Window slide of the trigger (model :392-393) in place: rows [drop, len) of every head move to the front (at most 64 rows stay). */
+/* Window slide of the trigger (model :392-393) in place: rows [drop, len) of every head move to the front
+ * (any number of rows may stay: overlapping ranges are moved in ascending pieces). */
 int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int64_t head_stride, int Bp, int len, int drop);
 
 /*
@@ -253,7 +254,7 @@ int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int
  *                         tables that the next decode launch will read), or NULL
  *   k_head_total / v_head_total / overflow_flag   as mustafar_cache_append_kv (the flags zeroed by the caller; one per layer)
  * mustafar_trigger_compress_batch: `scratch` = n x mustafar_compress_scratch_bytes(B', t) bytes; region_halfs as mustafar_cache_append_kv.
- * mustafar_trigger_finish_batch: `len` rows of every window are valid, `drop` (= t) leave; at most 64 rows stay.
+ * mustafar_trigger_finish_batch: `len` rows of every window are valid, `drop` (= t) leave; the rows that stay (any number) move to the front.
  */
 typedef struct mustafar_trigger_item {
     void* k_window;
@@ -289,8 +290,8 @@ int mustafar_get_fma_engine(void);
  * Structure of mustafar_decode_attention{,_view}: 1 = one-pass launch -- every wave runs key phase, softmax step and value
  * phase on its 64-token blocks and leaves (max, sum, unnormalised output) slabs that a row kernel merges (flash-decoding over
  * the compressed cache; needs ld_scores % 32 == 0, otherwise the other form runs); 0 = the round-1 form, key SpMV -> softmax
- * rows -> value SpMV -> sum; 2 (default) = by size: VALU engine one-pass while kv-heads x compressed tokens is small (launches
- * of tens of microseconds: c2, c3), two launches beyond (c4, c5); matrix-pipe engine one-pass at every size.  Also MUSTAFAR_ONEPASS=0|1|auto in the environment.  Same inputs, same
+ * rows -> value SpMV -> sum; 2 (default) = the one-pass launch at every size and for every group count
+ * (since round 3 it beats two launches at c2 .. c5 on all engines; the two-launch form runs when ld_scores % 32 != 0).  Also MUSTAFAR_ONEPASS=0|1|auto in the environment.  Same inputs, same
  * outputs within fp16 (the one-pass form normalises in fp32 at the end instead of rounding the probabilities to fp16).
  */
 int mustafar_set_onepass(int mode);

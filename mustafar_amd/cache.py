@@ -51,7 +51,7 @@ DEFAULT_SLACK = 0.03
 class ExtentPool:
     """ONE allocation holding the extents of one trigger of every layer (2 per layer: K, V -- all of one geometry: 256 tokens, the
     largest region any layer expects), their status words ([flag, K lengths, V lengths] per layer) and the compression scratch;
-    initialised by three launches.  The extents are `CompressedArena`s carved from it (they keep the allocation alive)."""
+    initialised by four launches.  The extents are `CompressedArena`s carved from it (they keep the allocation alive)."""
 
     def __init__(self, n_layers: int, heads: int, device, nz_cap: int):
         self.n, self.heads, self.device, self.nz_cap, self.used = n_layers, heads, device, nz_cap, False
@@ -68,6 +68,7 @@ class ExtentPool:
         w = self.buf[:ne * ext_bytes].view(torch.int32).view(ne, ext_bytes // 4)
         w[:, offs["nz_offset"] // 4:offs["nz_offset"] // 4 + heads] = _head_index(heads, device) * (nz_cap // 8)      # stream starts of the heads
         torch.as_strided(w, (ne, heads), (ext_bytes // 4, tiles + 1), offs["idx"] // 4).zero_()                         # offset 0 of every head
+        w[:, offs["totals"] // 4:offs["flag"] // 4 + 1].zero_()                                                          # the extents' OWN lengths / flag words (an in-place append into one would read them)
         self.status.zero_()                                                                                              # flags (and lengths)
         self._host = torch.empty((n_layers, self.status_words), dtype=torch.int64).pin_memory()                         # landing area of read_status()
 
@@ -306,7 +307,13 @@ class CompressedArena:
             if kr.shape != vr.shape or kr.dtype != torch.float16 or kr.dim() != 4 or kr.shape[0] * kr.shape[1] != ka.heads or kr.shape[3] != 128 \
                     or kr.shape[2] < window_len or window_len < 256 or not kr.is_contiguous() or not vr.is_contiguous() or kr.shape != rows[0][0].shape:
                 raise RuntimeError("append_extent_pairs expects contiguous fp16 [B, Hkv, rows >= window_len >= 256, 128] buffers of one shape")
-        if pool is None or pool.n != n or pool.heads != k0.heads or pool.used:
+        # a pool prepared some steps ahead is reused only if it still fits: same layers / heads / device, unused, and regions at least
+        # what every layer expects to append NOW (a short pool would only be caught by the overflow flag and a slow per-layer redo)
+        if pool is not None:
+            need = max(max(ka._expected_append(256, kth_k), va._expected_append(256, kth_v)) for ka, va in pairs)
+            if pool.n != n or pool.heads != k0.heads or pool.used or pool.device != k0.device or pool.nz_cap < _cap_nz(need, 0.0):
+                pool = None
+        if pool is None:
             pool = CompressedArena.prepare_extents(pairs, kth_k, kth_v)
         pool.used = True
         L = _lib.load()

@@ -645,25 +645,33 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
 }
 
 // Move the rows [drop, len) of every head's window to the front (model :392-393 slices and clones; here in place).
-// One workgroup per (head, side); the rows that stay are read in full before any is written, so the ranges may overlap.
-__global__ __launch_bounds__(kThreads) void window_drop_front_kernel(uint16_t* k_win, uint16_t* v_win, int64_t head_stride, int len, int drop)
+// One workgroup per (head, side).  The ranges may overlap (more rows stay than leave: a residual_length above 256), so the move goes in
+// ascending pieces of 4 x kThreads x 16 bytes, each read in full before it is written: a piece's destination lies below everything a
+// later piece reads.
+__device__ __forceinline__ void slide_rows(uint16_t* win, int len, int drop)
 {
-    uint16_t* win = (blockIdx.y ? v_win : k_win) + blockIdx.x * head_stride;
-    const int n16 = (len - drop) * (kD / 8);   // 16-byte pieces to move (<= 4 per thread: checked on the host)
+    const int n16 = (len - drop) * (kD / 8);   // 16-byte pieces to move
     const uint4* src = reinterpret_cast<const uint4*>(win + (int64_t)drop * kD);
     uint4* dst = reinterpret_cast<uint4*>(win);
-    uint4 v[4];
+    for (int base = 0; base < n16; base += 4 * kThreads) {   // (workgroup-uniform trip count: every thread reaches the barriers)
+        uint4 v[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int p = threadIdx.x + i * kThreads;
-        if (p < n16) v[i] = src[p];
-    }
-    __syncthreads();
+        for (int i = 0; i < 4; i++) {
+            const int p = base + threadIdx.x + i * kThreads;
+            if (p < n16) v[i] = src[p];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int p = threadIdx.x + i * kThreads;
-        if (p < n16) dst[p] = v[i];
+        for (int i = 0; i < 4; i++) {
+            const int p = base + threadIdx.x + i * kThreads;
+            if (p < n16) dst[p] = v[i];
+        }
+        __syncthreads();
     }
+}
+__global__ __launch_bounds__(kThreads) void window_drop_front_kernel(uint16_t* k_win, uint16_t* v_win, int64_t head_stride, int len, int drop)
+{
+    slide_rows((blockIdx.y ? v_win : k_win) + blockIdx.x * head_stride, len, drop);
 }
 
 // The tail of a trigger that grew the cache by an extent (cache.py: append_extent_pairs): the window slide of both sides and, by
@@ -678,22 +686,7 @@ __global__ __launch_bounds__(kThreads) void trigger_finish_kernel(uint16_t* k_wi
         if (slot) *slot = view;
     }
     if (drop <= 0 || len <= drop) return;
-    uint16_t* win = (blockIdx.y ? v_win : k_win) + blockIdx.x * head_stride;
-    const int n16 = (len - drop) * (kD / 8);   // 16-byte pieces to move (<= 4 per thread: checked on the host)
-    const uint4* src = reinterpret_cast<const uint4*>(win + (int64_t)drop * kD);
-    uint4* dst = reinterpret_cast<uint4*>(win);
-    uint4 v[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int p = threadIdx.x + i * kThreads;
-        if (p < n16) v[i] = src[p];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int p = threadIdx.x + i * kThreads;
-        if (p < n16) dst[p] = v[i];
-    }
+    slide_rows((blockIdx.y ? v_win : k_win) + blockIdx.x * head_stride, len, drop);
 }
 
 // Re-housing of a cache (cache.py: an arena moved into larger rows / regions): the three arrays of every head in ONE launch.
@@ -974,9 +967,7 @@ int mustafar_trigger_compress_batch(void* stream, int n, const mustafar_trigger_
 // slides both windows by `drop` rows (model :392-393).  Called once the caller has seen every flag clear.
 int mustafar_trigger_finish_batch(void* stream, int n, const mustafar_trigger_item* items, int64_t head_stride, int Bp, int len, int drop)
 {
-    if (n < 1 || !items || Bp < 1 || drop < 0 || len < drop || head_stride < (int64_t)len * kD ||
-        (int64_t)(len - drop) * (kD / 8) > 4 * kThreads)   // at most 64 rows stay (the hook keeps residual_length = 32)
-        return MUSTAFAR_EINVAL;
+    if (n < 1 || !items || Bp < 1 || drop < 0 || len < drop || head_stride < (int64_t)len * kD) return MUSTAFAR_EINVAL;
     for (int i = 0; i < n; i++)
         if (!items[i].k_window || !items[i].v_window) return MUSTAFAR_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1010,9 +1001,7 @@ int mustafar_cache_rehouse(void* stream, const mustafar_cache_view* src, const m
 
 int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int64_t head_stride, int Bp, int len, int drop)
 {
-    if (!k_window || !v_window || Bp < 1 || drop < 0 || len < drop || head_stride < (int64_t)len * kD ||
-        (int64_t)(len - drop) * (kD / 8) > 4 * kThreads)   // at most 64 rows stay (the hook keeps residual_length = 32)
-        return MUSTAFAR_EINVAL;
+    if (!k_window || !v_window || Bp < 1 || drop < 0 || len < drop || head_stride < (int64_t)len * kD) return MUSTAFAR_EINVAL;
     if (len == drop || drop == 0) return 0;
     window_drop_front_kernel<<<dim3(Bp, 2), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<uint16_t*>(k_window), static_cast<uint16_t*>(v_window), head_stride, len, drop);

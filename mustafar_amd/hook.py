@@ -168,9 +168,9 @@ class Window:
 
     @staticmethod
     def drop_front_pair(k_w: "Window", v_w: "Window", n: int):
-        """Slide both windows by n rows with one launch (at most 64 rows stay: the hook keeps residual_length of them)."""
+        """Slide both windows by n rows with one launch (the rows that stay -- residual_length of them -- move to the front)."""
         keep = k_w.len - n
-        if v_w.len != k_w.len or k_w.buf.shape != v_w.buf.shape or keep > 64 or not k_w.buf.is_cuda:
+        if v_w.len != k_w.len or k_w.buf.shape != v_w.buf.shape or not k_w.buf.is_cuda:
             k_w.drop_front(n)
             v_w.drop_front(n)
             return
@@ -408,6 +408,11 @@ class MustafarAttention:
             return out, (k_c, k_w, v_c, v_w, C, kv_seq_len - 1)   # lengths advance with the device counter
         k_w.len = v_w.len = w_len
         if defer_trigger:
+            # run_triggers() works on arena caches (a first trigger, C == 0, makes one when cfg.arena says so): anything else would
+            # come back with a cache of the wrong kind, or fail inside run_triggers -- refuse here
+            if not (use_arena or (cfg.arena and C == 0)):
+                raise RuntimeError("decode_fused(defer_trigger=True) needs an arena cache (MustafarConfig(arena=True)); "
+                                   "tuple caches run their trigger inside the step")
             return out, (k_c, k_w, v_c, v_w, C, kv_seq_len)
         if (kv_seq_len - cfg.residual_length - C) % 256 == 0 and w_len >= 256:                          # :324
             kth_k = compression.kth_from_sparsity(cfg.k_sparsity, D)
@@ -463,6 +468,9 @@ class MustafarAttention:
         due = [i for i, p in enumerate(pasts) if self.trigger_due(p)]
         if not due:
             return out
+        for i in due:
+            if not (isinstance(pasts[i][0], CompressedArena) or (cfg.arena and pasts[i][4] == 0)):
+                raise RuntimeError("run_triggers works on arena caches (MustafarConfig(arena=True)); a tuple cache runs its trigger inside decode()")
         batch = [i for i in due if self._batched_ok(pasts[i])]
         wl = {pasts[i][1].len for i in batch}
         if batch and len(wl) == 1 and len({pasts[i][1].buf.shape for i in batch}) == 1:

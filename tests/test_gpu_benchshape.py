@@ -24,7 +24,7 @@ import pytest
 import torch
 
 from oracle import oracle as orc
-from tests.util import fp16_bound
+from tests.util import DENSE_ULPS, NATIVE_ULPS, excess, fp16_bound
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -37,16 +37,6 @@ CASES = {  # BASELINE.json configs[1..4]: (Hq, Hkv, sparsity, L, batch)
     "s4": (32, 8, 0.7, 4096, 8),
     "s32": (32, 8, 0.7, 32768, 8),
 }
-DENSE_ULPS = 3.0    # fused vs fp32 dense attention: fp16 ulps of the output scale (the scores are rounded to fp16 twice on the way, model :278, :284)
-NATIVE_ULPS = 2.0   # fused vs the unfused call sequence (same score roundings; they differ in where the probabilities are normalised)
-
-
-def excess(got, want, ulps):
-    """max |got - want| in units of the bound `ulps` x 2^-11 x max|want| + 1e-4 (> 1: outside)."""
-    w = want.float()
-    scale = max(float(w.abs().max()), 2.0 ** -6)
-    err = float((got.float() - w).abs().max())
-    return err / (ulps * 2.0 ** -11 * scale + 1e-4) if math.isfinite(err) else float("inf")
 
 
 

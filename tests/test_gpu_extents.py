@@ -319,6 +319,42 @@ def test_batched_trigger_redoes_a_layer_whose_rows_are_full_of_ties():
         assert torch.equal(o_ref, o_bat)
 
 
+@pytest.mark.parametrize("residual", [128, 300])
+def test_batched_trigger_with_a_long_residual_window(residual):
+    """residual_length is the reference's config value (model :53, mem_spd_test.py:9 sets 32): with 128 or 300 rows staying behind a
+    trigger the slide moves more than the 64 rows the round-4 kernel was limited to -- at 300 the ranges overlap (more rows stay than
+    leave).  The batched trigger (run_triggers) and the layer-by-layer one (decode) must agree bit for bit, and both with dense
+    attention over oracle-pruned K / V."""
+    torch.manual_seed(14)
+    layers, bsz, hq, hkv, D = 2, 1, 8, 2, 128
+    attn = _attn(hq, hkv, residual_length=residual)
+    L0 = 256 + residual + 254                              # the second decode step reaches the trigger
+    K0 = [torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(layers)]
+    V0 = [torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(layers)]
+    ref_p = [attn.to_fused(attn.build_cache(K0[l].clone(), V0[l].clone())) for l in range(layers)]
+    bat_p = [attn.to_fused(attn.build_cache(K0[l].clone(), V0[l].clone())) for l in range(layers)]
+    Kall, Vall = [k.clone() for k in K0], [v.clone() for v in V0]
+    fired = 0
+    for step in range(4):
+        qkv = [tuple(torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv)) for _ in range(layers)]
+        for l in range(layers):
+            Kall[l] = torch.cat([Kall[l], qkv[l][1]], 2)
+            Vall[l] = torch.cat([Vall[l], qkv[l][2]], 2)
+            C = ref_p[l][4]
+            o_ref, ref_p[l] = attn.decode(*qkv[l], ref_p[l])
+            o_bat, bat_p[l] = attn.decode_fused(*qkv[l], bat_p[l], defer_trigger=True)
+            assert torch.equal(o_ref, o_bat), f"step {step} layer {l}"
+            want = _dense(qkv[l][0], Kall[l], Vall[l], C, 0.7, hq // hkv)
+            assert torch.allclose(o_bat.float(), want, rtol=4e-3, atol=2e-3)
+        if attn.trigger_due(bat_p[0]):
+            fired += 1
+            bat_p = attn.run_triggers(bat_p, attn.prepare_triggers(bat_p))
+        for l in range(layers):
+            assert bat_p[l][4] == ref_p[l][4] and bat_p[l][1].len == ref_p[l][1].len == bat_p[l][3].len
+            assert torch.equal(bat_p[l][1].view(), ref_p[l][1].view()) and torch.equal(bat_p[l][3].view(), ref_p[l][3].view())
+    assert fired == 1 and bat_p[0][4] == 512 and bat_p[0][1].len == residual + 2
+
+
 def test_a_device_side_T_needs_the_step_counter():
     """`t_device` sizes the launch for a capacity and is meant for captured graphs: an eager call (no `step_counter`) is refused with a
     clear error instead of launching at the capacity (and contradicting the eager mask-length check)."""

@@ -116,7 +116,7 @@ def test_batched_trigger_arguments_are_validated_without_a_gpu():
     assert L.mustafar_trigger_compress_batch(None, 2, items(), *(args[:-1] + (None,))) == 1      # no scratch
     assert L.mustafar_trigger_finish_batch(None, 2, items(v_window=None), 288 * 128, 8, 288, 256) == 1
     assert L.mustafar_trigger_finish_batch(None, 2, items(), 288 * 128, 8, 200, 256) == 1        # len < drop
-    assert L.mustafar_trigger_finish_batch(None, 2, items(), 288 * 128, 8, 400, 256) == 1        # more than 64 rows would stay / beyond the stride
+    assert L.mustafar_trigger_finish_batch(None, 2, items(), 288 * 128, 8, 400, 256) == 1        # rows beyond the head stride
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():

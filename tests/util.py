@@ -1,4 +1,6 @@
 """Shared helpers for the parity tests (CPU oracle side)."""
+import math
+
 import numpy as np
 
 from oracle import oracle as orc
@@ -20,3 +22,16 @@ def fp16_bound(ref64, sumabs):
     """|fp16(fp32-accumulated sum) - exact| for any summation order: one fp16 rounding of the result
     (2^-11 relative, doubled for slack) + fp32 accumulation noise proportional to sum|terms| + fp16 tiny."""
     return 2.0 ** -10 * np.abs(ref64) + 4e-6 * sumabs + 1e-7
+
+
+DENSE_ULPS = 3.0    # fused vs fp32 dense attention: fp16 ulps of the output scale (the scores are rounded to fp16 twice on the way, model :278, :284)
+NATIVE_ULPS = 2.0   # fused vs the unfused call sequence (same score roundings; they differ in where the probabilities are normalised)
+
+
+def excess(got, want, ulps):
+    """max |got - want| in units of the bound `ulps` x 2^-11 x max|want| + 1e-4 (> 1: outside).  Relative to the output SCALE, so that
+    one lost 64-token block shows at every cache length (an absolute atol of 2e-3 is the size of the outputs themselves at 32 k tokens)."""
+    w = want.float()
+    scale = max(float(w.abs().max()), 2.0 ** -6)
+    err = float((got.float() - w).abs().max())
+    return err / (ulps * 2.0 ** -11 * scale + 1e-4) if math.isfinite(err) else float("inf")

@@ -128,8 +128,8 @@ def main():
                 nb = 8
                 order = np.argsort(wg, kind="stable")
                 for name2, col in (("start", t[:, 0]), ("end", t[:, 6]), ("life", life)):
-                    parts = np.array_split(col[order], nb)
-                    print(f"     {name2:5s} by workgroup id, eighths (p50): " + " ".join(f"{np.median(x):6.2f}" for x in parts))
+                    eighths = np.array_split(col[order], nb)
+                    print(f"     {name2:5s} by workgroup id, eighths (p50): " + " ".join(f"{np.median(x):6.2f}" for x in eighths))
                 # age rank of a wave on its SIMD (by start time) against its end
                 simd = cu * 4 + ((hw >> np.uint64(4)) & np.uint64(3)).astype(np.int64)
                 ranks = np.zeros(len(r), dtype=np.int64)
