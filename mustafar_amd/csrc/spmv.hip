@@ -2189,7 +2189,12 @@ __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restr
 //   VAL = true  (value): chunks 0, 1 -> accA (channels 0..63), chunks 2, 3 -> accB (channels 64..127), lane = channel;
 //                        coefficient of a tile: the row's half (token % 64)
 //   bnd: the block's five chunk bounds (bnd_load), fetched by the caller ahead of time
-template <int ENG, int HS, bool VAL, int CB, int CN, int G = 4, class CBT = const void*>   // chunks [CB, CB + CN) of the block; G heads (G < 4: ENG 0)
+struct NoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int ENG, int HS, bool VAL, int CB, int CN, int G = 4, class CBT = const void*, int BOFF = 0, class MID = NoMid>   // chunks [CB, CB + CN) of the block; G heads (G < 4: ENG 0);
+                                                                                                      // BOFF: lane of `bnd` that holds the block's first bound;
+                                                                                                      // MID: called in front of the phase's LAST chunk (the caller's requests for what follows the phase)
 __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t lds_addr, const uint64_t* __restrict__ bmp_t,
                                                  const uint32_t* __restrict__ idx_t, const unsigned char* __restrict__ nz_h,
                                                  const CBT& cbase, uint32_t bnd, int lane, float (&accA)[G],
@@ -2198,6 +2203,7 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
                                                  , PhaseTrace& phase_trace_
 #endif
                                                  , uint32_t ctab_lane = 0   // ENG == 1: the LDS coefficient table (cbase unused)
+                                                 , const MID& mid = MID()
                                                  )
 {
     f32x4 mA = {0.f, 0.f, 0.f, 0.f}, mB = {0.f, 0.f, 0.f, 0.f};   // (ENG == 1 only)
@@ -2206,8 +2212,8 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
 #pragma unroll
         for (int h = 0; h < G; h++) { mA[h] = accA[h]; mB[h] = accB[h]; }
     }
-    uint32_t i0 = bnd_get(bnd, CB);
-    const uint32_t len0 = 4u * (bnd_get(bnd, CB + 1) - i0);
+    uint32_t i0 = bnd_get(bnd, BOFF + CB);
+    const uint32_t len0 = 4u * (bnd_get(bnd, BOFF + CB + 1) - i0);
     Stage st = stage_issue<ENG == 1>(nz_h + 4ull * i0, len0, lane);
     stage_commit<ENG == 1>(lds, st, lane, len0);
 #ifdef MUSTAFAR_WAVE_TRACE
@@ -2218,10 +2224,11 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
     for (int c = CB; c < CB + CN; c++) {
         uint32_t n0 = 0, nlen = 0;
         if (c < CB + CN - 1) {
-            n0 = bnd_get(bnd, c + 1);
-            nlen = 4u * (bnd_get(bnd, c + 2) - n0);
+            n0 = bnd_get(bnd, BOFF + c + 1);
+            nlen = 4u * (bnd_get(bnd, BOFF + c + 2) - n0);
             st = stage_issue<ENG == 1>(nz_h + 4ull * n0, nlen, lane);
         }
+        if (c == CB + CN - 1) mid();
         __builtin_amdgcn_wave_barrier();
 #ifdef MUSTAFAR_PROBE_HOTMETA
         const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr);   // the fixed offsets of g_hot_idx stay inside the window
@@ -2666,6 +2673,358 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
     MUSTAFAR_PTRACE_END(7);
 }
 
+// ------------------------------------------------------------------------------------------------ one-pass decode, SUPER-BLOCK pair form (round 5)
+// decode_onepass_leanpair_kernel with the code AROUND the two phases cut down (profiles/r05_isa_breakdown.txt: 2.07 of its 8.78 vector
+// instructions per tile sat there -- 85 v_readlane / v_writelane of spilled scalars, a softmax step per block and head with twelve DPP
+// reductions, 23 v_cndmask selecting the even / odd wave's registers, the address arithmetic of the metadata prefetch):
+//   * a pair of waves takes TWO consecutive blocks as one 128-token super-block: key phase A, key phase B, ONE softmax step over the
+//     128 tokens (one maximum per head: one DPP reduction instead of two), value phase A, value phase B.  At four blocks per workgroup
+//     (every BASELINE shape) a pair runs its loop once: no running maximum, no rescale factors, no exchange of them, two barriers per
+//     workgroup instead of four; longer loops keep the online form;
+//   * the softmax denominator stays per LANE and is summed over the lanes once behind the loop (no DPP reduction in the step);
+//   * one body for both waves of a pair: the odd wave's pointers are biased by its 64 tiles / 64 channels once, in front of the loop, so that
+//     the phase code (lean_block_phase<.., 0, 2>) and every register choice are the same for both -- the phases are in the kernel's text
+//     twice instead of four times and nothing is selected per lane;
+//   * the partial scores cross through LDS whole ([block][lane][G] floats in the wave's own stage window, dead between its key and value
+//     phases) and every wave reads back the two heads it finishes -- its own contribution and the partner's -- at an address that carries
+//     the head offset: no register selection;
+//   * bounds + offset-line prefetch are ONE saddr-form load (lane k < 3: bound k; lanes 3, 4: the lines in between), the bitmap-line
+//     prefetch another: no vector address arithmetic;
+//   * MASK is a template parameter (the unmasked launch carries no mask arithmetic).
+// Same grid, slabs and window workgroups as decode_onepass_leanpair_kernel: a drop-in for it (`mustafar_tune(8, 0)` selects the old kernel).
+#ifndef MUSTAFAR_SB_PRIO
+#define MUSTAFAR_SB_PRIO 2   // s_setprio 1 from the start of a trip to: 1 = the end of its key phases, 2 = the end of its softmax step, 3 = the end of
+                             // its first value phase; 0 = never raised (experiment knob: tools/build_variant.sh)
+#endif
+template <int W>
+struct FVec;
+template <> struct FVec<1> { typedef float type; };
+template <> struct FVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct FVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// m = max over the wave of max(x, floor) (floor: a wave-uniform value in a scalar register), in a scalar register
+__device__ __forceinline__ float wave_max_from(float x, float floor_s)
+{
+    asm("v_max_f32 %0, %1, %0\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(x)
+        : "s"(floor_s));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+// a dword at (uniform base) + (per-lane byte offset): global_load_dword v, v_off, s[base] -- no address arithmetic
+__device__ __forceinline__ uint32_t ld_at(const void* __restrict__ sbase, uint32_t voff)
+{
+    return *reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(sbase) + voff);
+}
+template <int ENG, bool EXT = false, int G = 4, bool MASK = false, bool MULTI = false>   // MULTI: a pair may walk more than one super-block (the online form)
+__global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
+    const uint64_t* __restrict__ k_bmp, const unsigned char* __restrict__ k_nz, const uint32_t* __restrict__ k_idx,
+    const uint32_t* __restrict__ k_nz_off, const uint64_t* __restrict__ v_bmp, const unsigned char* __restrict__ v_nz,
+    const uint32_t* __restrict__ v_idx, const uint32_t* __restrict__ v_nz_off, OneArgs a, int64_t k_bmp_stride,
+    int64_t k_idx_stride, uint32_t k_nz_stride, int64_t v_bmp_stride, int64_t v_idx_stride, uint32_t v_nz_stride)
+{
+    static_assert(G == 4 || ENG == 0, "dot2 and the matrix pipe work on four heads; G < 4 runs v_fma_mix");
+    constexpr int HW = G >= 2 ? G / 2 : 1;   // heads a wave of the pair finishes (G = 1: the even wave its one head, the odd wave none)
+    constexpr int kTabBytes = ENG == 1 ? 4 * kKeyTabStride + 2 * 2 * 4 * kValTabStride : 0;   // q rows; per pair TWO e tables (blocks A, B)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes + 2 * G * 4];   // (+ the pairs' rescale factors)
+    typedef typename FVec<G>::type fvG;
+    typedef typename FVec<HW>::type fvH;
+    MUSTAFAR_PTRACE_BEGIN();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wrows = a.win_rows < 0 ? -a.win_rows : a.win_rows;   // window rows lead (win_rows > 0) or trail (< 0) the grid
+    const int wy = a.win_rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
+    if (wy >= 0 && wy < wrows) {   // dense window
+        const int task = wy * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wrows) * a.nchunks) {
+            int T_used = -1;
+            if constexpr (EXT) { if (a.t_dev) T_used = __builtin_amdgcn_readfirstlane(*a.t_dev); }
+            onepass_window_wg<G>(smem, win_args(a, T_used), task, gridDim.x);
+        }
+        MUSTAFAR_PTRACE_END(5);
+        return;
+    }
+    const int by = blockIdx.y - (a.win_rows > 0 ? a.win_rows : 0);
+    const int hb_per_kv = a.groups / G;
+    const int kvh = hb_per_kv == 1 ? by : by / hb_per_kv;
+    const int bh0 = kvh * a.groups + (by - kvh * hb_per_kv) * G;
+    const int ntb_cap = a.T >> 6;   // what the launch was sized for
+    int ntb = ntb_cap;              // blocks in use
+    if constexpr (EXT) { if (a.t_dev) ntb = min(ntb_cap, __builtin_amdgcn_readfirstlane(*a.t_dev) >> 6); }
+    const int tb0 = blockIdx.x * a.tb_per_wg;
+    const int tb_end = min(ntb, tb0 + a.tb_per_wg);
+    if constexpr (EXT) {
+        if (tb0 >= ntb) {   // a workgroup beyond the tokens in use (the cache has not grown into its blocks yet): a slab of weight zero
+            float* so = a.ws_o + ((int64_t)blockIdx.x * a.BH + bh0) * kD;
+#pragma unroll
+            for (int o = 0; o < G * kD; o += kThreads) so[o + (threadIdx.x & (G * kD - 1) & (kThreads - 1))] = 0.f;   // (G = 1: 128 floats, stored twice)
+            *reinterpret_cast<float2*>(a.ws_ml + ((int64_t)blockIdx.x * a.BH + bh0 + (threadIdx.x & (G - 1))) * 2) = make_float2(-INFINITY, 0.f);
+            MUSTAFAR_PTRACE_END(7);
+            return;
+        }
+    }
+    const int pair = wave >> 1;
+    const int odd = wave & 1;
+    // the pair's blocks: the first pair takes the first half of the workgroup's blocks (rounded up), the second pair the rest; both walk
+    // theirs two at a time, `trips` times (workgroup-uniform: every wave reaches the barriers)
+    const int nblk = tb_end - tb0;
+    const int nfirst = (nblk + 1) >> 1;
+    const int pb0 = tb0 + (pair ? nfirst : 0);
+    const int pb_end = pair ? tb_end : tb0 + nfirst;
+    const int trips = (nfirst + 1) >> 1;
+    const int64_t tiles = (int64_t)(EXT ? a.nb0 : ntb) * kTilesPerTb;
+    const uint64_t* kb;
+    const uint32_t* ki;
+    const unsigned char* kn;
+    const uint64_t* vb;
+    const uint32_t* vi;
+    const unsigned char* vn;
+    if (EXT && tb0 >= a.nb0) {
+        // a workgroup of an appended extent (its blocks never straddle two: extents are four blocks, workgroups two or four): the extent's
+        // arrays, biased so that `+ tb * 128` lands inside them
+        const int e = (tb0 - a.nb0) >> 2;
+        const mustafar_cache_view ek = a.k_ext[e], ev = a.v_ext[e];
+        const int64_t t0 = (int64_t)(a.nb0 + 4 * e) * kTilesPerTb;
+        kb = uniform_ptr(ek.bmp + (int64_t)kvh * ek.bmp_head_stride - t0);
+        ki = uniform_ptr(ek.idx + (int64_t)kvh * ek.idx_head_stride - t0);
+        kn = uniform_ptr(static_cast<const unsigned char*>(ek.nz) + 16ull * (uint64_t)kvh * (uint64_t)ek.nz_head_stride);
+        vb = uniform_ptr(ev.bmp + (int64_t)kvh * ev.bmp_head_stride - t0);
+        vi = uniform_ptr(ev.idx + (int64_t)kvh * ev.idx_head_stride - t0);
+        vn = uniform_ptr(static_cast<const unsigned char*>(ev.nz) + 16ull * (uint64_t)kvh * (uint64_t)ev.nz_head_stride);
+    } else {
+        kb = k_bmp + (int64_t)kvh * (k_bmp_stride ? k_bmp_stride : tiles);
+        ki = k_idx + (int64_t)kvh * (k_idx_stride ? k_idx_stride : tiles + 1);
+        kn = k_nz + 16ull * (k_nz_stride ? (uint64_t)kvh * k_nz_stride : (uint64_t)k_nz_off[kvh]);
+        vb = v_bmp + (int64_t)kvh * (v_bmp_stride ? v_bmp_stride : tiles);
+        vi = v_idx + (int64_t)kvh * (v_idx_stride ? v_idx_stride : tiles + 1);
+        vn = v_nz + 16ull * (v_nz_stride ? (uint64_t)kvh * v_nz_stride : (uint64_t)v_nz_off[kvh]);
+    }
+    // ---- one body for both waves of a pair: the odd wave's half (tiles 64..127 of every block; channels 64..127 of the q rows) is a bias
+    kb += odd * 64;
+    ki += odd * 64;
+    vb += odd * 64;
+    vi += odd * 64;
+    const h16* qb = a.q + (int64_t)bh0 * kD + odd * 64;
+    h16* eb = a.e_rows + (int64_t)by * ntb_cap * (G * 64);
+    const h16* mrow = nullptr;
+    if constexpr (MASK) mrow = a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride;
+    unsigned char* lds = smem + wave * kStageBytes;
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    const int h0 = (odd && G >= 2) ? HW : 0;   // my heads: h0 .. h0 + HW - 1
+    const bool has_heads = G >= 2 || !odd;
+    // partial scores, whole: [block A | block B][lane][G] floats in my window; I read back my heads' [HW] floats of mine and the partner's
+    fvG* xch_out = reinterpret_cast<fvG*>(lds) + lane;                                                       // (+ 64 for block B)
+    const float* xch_mine = reinterpret_cast<const float*>(lds) + lane * G + h0;                               // (+ 64 * G for block B)
+    const float* xch_part = reinterpret_cast<const float*>(smem + (wave ^ 1) * kStageBytes) + lane * G + h0;
+    float* alf = reinterpret_cast<float*>(smem + kWaves * kStageBytes + kTabBytes) + pair * G;
+    constexpr float kEScaleLog2 = ENG == 2 ? 15.f : 0.f;
+    // per-lane byte offsets of the two metadata loads of a phase (no address arithmetic at the call sites):
+    //   bounds + offset lines: lane k < 3 reads idx[32 k] (the wave's three chunk bounds), lanes 3 / 4 the 64-byte lines in between
+    //   bitmap lines: 64 tiles x 8 bytes = eight 64-byte lines
+    // (lanes 0..7 serve block A, lanes 8..15 -- the same offsets -- block B of the super-block: one register holds both blocks' bounds)
+    const uint32_t off_bnd = (lane & 7) < 3 ? (lane & 7) * 128u : ((lane & 7) == 3 ? 64u : 192u);
+    const uint32_t off_bmp = (lane & 7) * 64u;
+    const bool lanesB = lane >= 8 && lane < 16;
+
+    uint32_t ctab_q = 0, ctab_e = 0;
+    unsigned char* ptab = nullptr;   // matrix-pipe engine: the pair's e tables (blocks A, B): e stays in LDS
+    if constexpr (ENG == 1) {
+        unsigned char* tab = smem + kWaves * kStageBytes;
+        if (threadIdx.x < 64)
+            *reinterpret_cast<uint4*>(tab + (threadIdx.x >> 4) * kKeyTabStride + (threadIdx.x & 15) * 16) =
+                *reinterpret_cast<const uint4*>(a.q + (int64_t)bh0 * kD + (int64_t)(threadIdx.x >> 4) * kD + (threadIdx.x & 15) * 8);
+        __syncthreads();
+        ptab = tab + 4 * kKeyTabStride + pair * (2 * 4 * kValTabStride);
+        ctab_q = (uint32_t)reinterpret_cast<uintptr_t>(tab) + (lane & 3) * kKeyTabStride + odd * 128;
+        ctab_e = (uint32_t)reinterpret_cast<uintptr_t>(ptab) + (lane & 3) * kValTabStride;
+    }
+    float m_run[HW], l_lane[HW], acc[G];   // acc: the wave's output half (even: channels 0..63, odd: 64..127); m_run (uniform), l_lane (per lane): my heads
+#pragma unroll
+    for (int h = 0; h < G; h++) acc[h] = 0.f;
+#pragma unroll
+    for (int j = 0; j < HW; j++) { m_run[j] = -INFINITY; l_lane[j] = 0.f; }
+    if (MUSTAFAR_SB_PRIO) __builtin_amdgcn_s_setprio(1);
+    asm volatile("; sb_trips_begin");   // (markers for tools/isa_breakdown.py --markers: a comment in the ISA, no instruction)
+#pragma unroll 1
+    for (int trip = 0; trip < (MULTI ? trips : 1); trip++) {
+        const int tA = pb0 + 2 * trip;
+        const bool actA = tA < pb_end, actB = tA + 1 < pb_end;   // (wave-uniform)
+        const int tAc = actA ? tA : tb0;                          // (an idle pair addresses the workgroup's first block and computes nothing)
+        const int tBc = actB ? tA + 1 : tAc;
+        h16* eA = eb + (int64_t)tAc * (G * 64);
+        h16* eB = eb + (int64_t)tBc * (G * 64);
+        float sA[G], sB[G];
+#pragma unroll
+        for (int h = 0; h < G; h++) { sA[h] = 0.f; sB[h] = 0.f; }
+        uint32_t bndV = 0;   // bounds of the value side: block A in lanes 0..2, block B in lanes 8..10
+        uint32_t pfVA = 0;   // (the value of a metadata-line prefetch is never used; it is held to the end of the phase it was made for)
+        h16 mkA = (h16)0.f, mkB = (h16)0.f;
+        const uint64_t* vbA = vb + (int64_t)tAc * kTilesPerTb;
+        const uint32_t* viA = vi + (int64_t)tAc * kTilesPerTb;
+        // What a phase needs from memory before its stream -- its three chunk bounds and its metadata lines in L2 -- is requested in
+        // front of the LAST chunk of the phase before it (~2-3 us ahead: sooner and the lines are gone from L2 again by the time the
+        // scalar loads come for them, later and the phase starts with two dependent round trips)
+        if (actA) {
+            const uint64_t* kbA = kb + (int64_t)tAc * kTilesPerTb;
+            const uint32_t* kiA = ki + (int64_t)tAc * kTilesPerTb;
+            uint32_t bndK = ld_at(kiA, off_bnd);
+            const uint32_t pfKA = ld_at(kbA, off_bmp);
+            if constexpr (MASK) {
+                mkA = mrow[tAc * 64 + lane];
+                if (actB) mkB = mrow[tBc * 64 + lane];
+            }
+            auto reqVA = [&]() {
+                bndV = ld_at(viA, off_bnd);
+                pfVA = ld_at(vbA, off_bmp);
+            };
+            if (actB) {
+                uint32_t pfKB = 0;
+                auto reqKB = [&]() {
+                    if (lanesB) bndK = ld_at(kiA + kTilesPerTb, off_bnd);
+                    pfKB = ld_at(kbA + kTilesPerTb, off_bmp);
+                };
+                lean_block_phase<ENG, kD * 2, false, 0, 2, G, const void*, 0>(lds, lds_addr, kbA, kiA, kn, qb, bndK, lane, sA, sA MUSTAFAR_PTRACE_ARG, ctab_q, reqKB);
+                prefetch_done(pfKA);
+                lean_block_phase<ENG, kD * 2, false, 0, 2, G, const void*, 8>(lds, lds_addr, kbA + kTilesPerTb, kiA + kTilesPerTb, kn, qb, bndK, lane, sB, sB MUSTAFAR_PTRACE_ARG, ctab_q, reqVA);
+                prefetch_done(pfKB);
+            } else {
+                lean_block_phase<ENG, kD * 2, false, 0, 2, G, const void*, 0>(lds, lds_addr, kbA, kiA, kn, qb, bndK, lane, sA, sA MUSTAFAR_PTRACE_ARG, ctab_q, reqVA);
+                prefetch_done(pfKA);
+            }
+            fvG oA, oB;
+            if constexpr (G == 1) { oA = sA[0]; oB = sB[0]; }
+            else {
+#pragma unroll
+                for (int h = 0; h < G; h++) { oA[h] = sA[h]; oB[h] = sB[h]; }
+            }
+            xch_out[0] = oA;
+            xch_out[64] = oB;
+        }
+        if (MUSTAFAR_SB_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        MUSTAFAR_PTRACE_STAMP(2);
+        __syncthreads();
+        if (actA && has_heads) {
+            const fvH mineA = *reinterpret_cast<const fvH*>(xch_mine), partA = *reinterpret_cast<const fvH*>(xch_part);
+            const fvH mineB = *reinterpret_cast<const fvH*>(xch_mine + 64 * G), partB = *reinterpret_cast<const fvH*>(xch_part + 64 * G);
+            float al[HW] = {};
+#pragma unroll
+            for (int j = 0; j < HW; j++) {
+                float pa, pb;
+                if constexpr (HW == 1) { pa = mineA + partA; pb = mineB + partB; }
+                else                   { pa = mineA[j] + partA[j]; pb = mineB[j] + partB[j]; }
+                float xa = scaled((h16)pa, a.inv_sqrt_d);   // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
+                float xb = scaled((h16)pb, a.inv_sqrt_d);
+                if constexpr (MASK) { xa = masked(xa, mkA); xb = masked(xb, mkB); }
+                if (!actB) xb = -INFINITY;
+                const float m_new = wave_max_from(fmaxf(xa, xb), m_run[j]);
+                const h16 ea = (h16)__builtin_amdgcn_exp2f((xa - m_new) * 1.44269504f + kEScaleLog2);
+                const h16 eb2 = (h16)__builtin_amdgcn_exp2f((xb - m_new) * 1.44269504f + kEScaleLog2);
+                if constexpr (ENG == 1) {
+                    *reinterpret_cast<h16*>(ptab + (h0 + j) * kValTabStride + lane * 2) = ea;
+                    *reinterpret_cast<h16*>(ptab + 4 * kValTabStride + (h0 + j) * kValTabStride + lane * 2) = eb2;
+                } else {
+                    eA[(h0 + j) * 64 + lane] = ea;
+                    if (actB) eB[(h0 + j) * 64 + lane] = eb2;
+                }
+                if constexpr (MULTI) {
+                    if (trip) {   // a later trip of a longer loop: the online form (running maximum, rescaled sums and outputs)
+                        al[j] = uniform_f(__expf(m_run[j] - m_new));
+                        l_lane[j] *= al[j];
+                    }
+                }
+                l_lane[j] += (float)ea + (float)eb2;
+                m_run[j] = m_new;
+            }
+            if constexpr (MULTI) {
+                if (trip) {
+                    if constexpr (HW == 2) { if (lane < 2) alf[h0 + lane] = lane ? al[1] : al[0]; }
+                    else                   { if (lane < 1) alf[h0] = al[0]; }
+                }
+            }
+            if constexpr (ENG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my e stores have reached L2 before the pair's scalar loads
+        }
+        if (MUSTAFAR_SB_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        MUSTAFAR_PTRACE_STAMP(3);
+        if (actA) {
+            if constexpr (MULTI) {
+                if (trip) {
+                    const fvG al4 = *reinterpret_cast<const fvG*>(alf);
+#pragma unroll
+                    for (int h = 0; h < G; h++) {
+                        if constexpr (G == 1) acc[h] *= al4;
+                        else                  acc[h] *= al4[h];
+                    }
+                }
+            }
+            // (the partner read my outgoing partial scores before the barrier above; my value phase now rewrites the window)
+            if (actB) {
+                uint32_t pfVB = 0;
+                auto reqVB = [&]() {
+                    if (lanesB) bndV = ld_at(viA + kTilesPerTb, off_bnd);
+                    pfVB = ld_at(vbA + kTilesPerTb, off_bmp);
+                };
+                lean_block_phase<ENG, 64 * 2, true, 0, 2, G, const void*, 0>(lds, lds_addr, vbA, viA, vn, eA, bndV, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e, reqVB);
+                prefetch_done(pfVA);
+                if (MUSTAFAR_SB_PRIO == 3) __builtin_amdgcn_s_setprio(0);
+                lean_block_phase<ENG, 64 * 2, true, 0, 2, G, const void*, 8>(lds, lds_addr, vbA + kTilesPerTb, viA + kTilesPerTb, vn, eB, bndV, lane, acc, acc MUSTAFAR_PTRACE_ARG,
+                                                                             ctab_e + 4 * kValTabStride);
+                prefetch_done(pfVB);
+            } else {
+                lean_block_phase<ENG, 64 * 2, true, 0, 2, G, const void*, 0>(lds, lds_addr, vbA, viA, vn, eA, bndV, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
+                prefetch_done(pfVA);
+            }
+        }
+        MUSTAFAR_PTRACE_STAMP(5);
+    }
+    asm volatile("; sb_trips_end");
+    // ---- the softmax denominators: summed over the lanes once
+    float l_run[HW];
+#pragma unroll
+    for (int j = 0; j < HW; j++) l_run[j] = wave_sum(l_lane[j]);
+    // ---- merge the two pairs: common maximum, rescaled sums and output halves -> one slab per head (as decode_onepass_leanpair_kernel)
+    float* red = reinterpret_cast<float*>(smem);                 // [kWaves][G][64]
+    float* s_m = red + kWaves * G * 64;                          // [2 pairs][G]
+    float* s_l = s_m + 2 * G;                                    // [2 pairs][G]
+    __syncthreads();   // every wave is done with its stage window
+    if (has_heads && lane < HW) s_m[pair * G + h0 + lane] = lane ? m_run[HW - 1] : m_run[0];   // (each wave: the maxima of its heads)
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        const float mw = s_m[pair * G + h];                      // the PAIR's maximum of head h (kept by one of its two waves)
+        const float M = fmaxf(s_m[h], s_m[G + h]);
+        // a pair without blocks weighs nothing; the e scale leaves here (a power of two: exact)
+        const float scale = (mw == -INFINITY) ? 0.f : __expf(mw - M) * (ENG == 2 ? 0x1p-15f : 1.f);
+        if (lane == 0 && has_heads && h / HW == (G >= 2 ? odd : 0)) s_l[pair * G + h] = l_run[h % HW] * scale;   // (the wave that finished head h)
+        red[(wave * G + h) * 64 + lane] = acc[h] * scale;
+    }
+    __syncthreads();
+    float* slab_o = a.ws_o + ((int64_t)blockIdx.x * a.BH + bh0) * kD;
+    for (int o = threadIdx.x; o < 2 * G * 64; o += kThreads) {
+        const int hh = o >> 6, l = o & 63;   // hh = half * G + h; waves `half` and `half + 2` hold that half
+        const int half = hh / G, h = hh % G;
+        slab_o[h * kD + half * 64 + l] = red[(half * G + h) * 64 + l] + red[((half + 2) * G + h) * 64 + l];
+    }
+    if (threadIdx.x < G) {
+        const int h = threadIdx.x;
+        float* slab_ml = a.ws_ml + ((int64_t)blockIdx.x * a.BH + bh0 + h) * 2;
+        slab_ml[0] = fmaxf(s_m[h], s_m[G + h]);
+        slab_ml[1] = s_l[h] + s_l[G + h];
+    }
+    MUSTAFAR_PTRACE_END(7);
+}
+
 // ------------------------------------------------------------------------------------------------ key SpMV, lean pair form (round 4)
 // The reference entry point Key_SplitK_API (kernel/csrc/SpMM_API.cu:86-139 -> Key_Kernel, SpMM_Kernel.cuh:156-419) on the machinery
 // of the one-pass launch's key phase: two waves share a 64-token block (64 channels each, partial scores folded through LDS), every
@@ -2951,6 +3310,7 @@ inline int onepass_target_wgs(bool pair)
 // GQA-4 one-pass launches on the vector engines: MUSTAFAR_ONEPASS_LEAN=2 (default) the lean kernel at the pair grain, 1 the lean
 // kernel with whole blocks per wave, 0 the round-2 pair form; MUSTAFAR_LEAN_TBW=n: blocks per wave (1) / block pairs per
 // workgroup (2) instead of the automatic choice (raised when the slabs would not fit).
+int g_sb = [] { const char* e = getenv("MUSTAFAR_SB"); return e ? atoi(e) != 0 : 1; }();   // round 5: the super-block pair form (mustafar_tune(8, 0): round 4's pair kernel)
 int g_pair_slabs = 0;   // pair form, mustafar_tune(4, 1): a slab per pair instead of one per workgroup (kernel 1.1 us shorter at c3, row kernel 1.5 us longer)
 // g_lean_win_last: the pair form's window workgroups sit BEHIND the SpMV rows of the grid (mustafar_tune(3, 0): in front, round 3a).
 // In front they hold 434 of the chip's 2048 workgroup slots for their ~10 us while the SpMV rows wait; behind, they fill the tail
@@ -3315,7 +3675,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                 per_wg = kWaves * (onepass_lean_tbw() > 0 ? onepass_lean_tbw() : 1);
             }
             const int step = lp ? 2 : kWaves;
-            const int spw = lp && g_pair_slabs ? 2 : 1;   // slabs per workgroup
+            const int spw = lp && g_pair_slabs && !(g_sb && per_wg <= 4) ? 2 : 1;   // slabs per workgroup (the super-block form always merges its pairs)
             while (spw * ((ntb + per_wg - 1) / per_wg) + nchunks > kMaxSlabs) per_wg += step;
             const int S1 = (ntb + per_wg - 1) / per_wg;   // workgroups per head group
             const int NS = spw * S1;                      // their slabs
@@ -3351,8 +3711,20 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                 // never touches, and a kernel with a private segment is launched with scratch (+1 % measured on the GQA-4 form); the
                 // extents instantiation has none and serves the same launch with every block in the base views)
                 if (!extents && G == 1) a.nb0 = ntb;
-                if (extents || G == 1) MUSTAFAR_LP(true);
-                else                   MUSTAFAR_LP(false);
+                if (g_sb && per_wg <= 4) {   // round 5: the super-block pair form (same grid, slabs and window workgroups; a pair walks its <= 2 blocks once)
+#define MUSTAFAR_SB(EXTV, MASKV)                                                                            \
+    do {                                                                                                    \
+        if (G == 2)        MUSTAFAR_LL((decode_onepass_sb_kernel<0, EXTV, 2, MASKV>));                       \
+        else if (G == 1)   MUSTAFAR_LL((decode_onepass_sb_kernel<0, EXTV, 1, MASKV>));                       \
+        else if (eng == 2) MUSTAFAR_LL((decode_onepass_sb_kernel<2, EXTV, 4, MASKV>));                       \
+        else if (eng == 1) MUSTAFAR_LL((decode_onepass_sb_kernel<1, EXTV, 4, MASKV>));                       \
+        else               MUSTAFAR_LL((decode_onepass_sb_kernel<0, EXTV, 4, MASKV>));                       \
+    } while (0)
+                    if (extents || G == 1) { if (mask.ptr) MUSTAFAR_SB(true, true); else MUSTAFAR_SB(true, false); }
+                    else                   { if (mask.ptr) MUSTAFAR_SB(false, true); else MUSTAFAR_SB(false, false); }
+#undef MUSTAFAR_SB
+                } else if (extents || G == 1) MUSTAFAR_LP(true);
+                else                          MUSTAFAR_LP(false);
 #undef MUSTAFAR_LP
             } else {
                 if (fma_engine() == 2) MUSTAFAR_LL((decode_onepass_lean_kernel<2>));
@@ -3614,6 +3986,7 @@ int mustafar_tune(int knob, int value)
         case 4: g_pair_slabs = value ? 1 : 0; return 0;
         case 6: g_key_lean = value ? 1 : 0; return 0;
         case 7: g_value_lean = value ? 1 : 0; return 0;
+        case 8: g_sb = value ? 1 : 0; return 0;
         default: return MUSTAFAR_EINVAL;
     }
 }

@@ -132,6 +132,7 @@ import math, sys, torch
 sys.path.insert(0, {root!r})
 from mustafar_amd.hook import MustafarAttention, MustafarConfig
 from tests.test_gpu_hook import _dense_reference
+from tests.util import DENSE_ULPS, excess
 torch.manual_seed(11)
 dev, bsz, hq, hkv, D, L0 = "cuda:0", 2, 8, 2, 128, 600
 cfg = MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, api="fused")

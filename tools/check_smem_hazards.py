@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Static checks of the SpMV kernels' ISA.
 
-(1) No instruction reads an SGPR that a scalar load still has in flight.
+(1) No instruction reads an SGPR that a scalar load still has in flight (control-flow aware since round 5: basic blocks, the
+pending set propagated forward with a union at joins).
 
 The inner loop issues `s_load_dword*` inside asm statements and waits later (`s_waitcnt lgkmcnt(0)`); the compiler does not
 know those registers are pending, so nothing but our own placement keeps it from copying or spilling them (`s_mov`,
@@ -17,7 +18,11 @@ ends, with no branch or barrier in between; and at the statement's entry EXEC mu
 code shows -- the statement may not sit inside a compiler-made divergent region (`s_and_saveexec` .. `s_or_b64 exec`), where
 the restoring -1 would switch lanes on that the program had switched off.
 
-    python tools/check_smem_hazards.py        # exit code 1 on a hazard
+(3) The prefetch sink (round 5, pf_at() in spmv.hip): loads whose value is never used are issued inside asm statements into ONE
+register per kernel that the compiler does not know is pending; all of a kernel's sink loads must name the same register and no
+other instruction of the kernel may write it.
+
+    python tools/check_smem_hazards.py [file.s]   # exit code 1 on a hazard; without a file spmv.hip is compiled
 """
 import os
 import re
@@ -38,78 +43,233 @@ def sgprs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def check(asm_text):
-    hazards, kernel, pending = [], None, set()
-    loads = waits = 0
-    in_asm = exec_masked = False    # inside an asm statement / inside its bitmap-masked stretch
-    divergent = 0                   # depth of compiler-made divergent regions (saveexec .. or exec)
-    exec_stretches = 0
+def vgprs(tok):
+    """'v[2:5]' -> {2..5}; 'v7' -> {7}; anything else -> empty."""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def _kernels(asm_text):
+    """[(kernel name, [(line number, code, in_asm)])]: instructions and .LBB labels of every function, in text order."""
+    out, cur, in_asm = [], None, False
     for ln, line in enumerate(asm_text.splitlines(), 1):
         if "#ASMSTART" in line:
             in_asm = True
+            if cur is not None:
+                cur.append((ln, "#ASMSTART", True))
             continue
         if "#ASMEND" in line:
-            if exec_masked:
-                hazards.append((kernel, ln, "asm statement ends with a bitmap in EXEC"))
-            in_asm = exec_masked = False
+            in_asm = False
+            if cur is not None:
+                cur.append((ln, "#ASMEND", True))
+            continue
+        if "sink_end" in line and cur is not None:
+            cur.append((ln, "#SINKEND", True))
             continue
         code = line.split(";")[0].strip()
         if not code:
             continue
         if code.endswith(":") and not code.startswith("."):
-            if not code.startswith(".L") and not code.startswith("BB"):
-                kernel, pending, divergent = code[:-1], set(), 0
+            cur = []
+            out.append((code[:-1], cur))
             continue
-        if code.startswith("."):
+        if code.startswith(".") and not (code.startswith(".LBB") and code.endswith(":")):
             continue
-        parts = code.replace(",", " ").split()
-        op, args = parts[0], parts[1:]
-        # ---- (2) EXEC discipline
-        if in_asm:
-            if op == "s_mov_b64" and args and args[0] == "exec":
-                if args[1] == "-1":
-                    exec_stretches += exec_masked
-                    exec_masked = False
-                else:
-                    if divergent:
-                        hazards.append((kernel, ln, "EXEC-masking asm statement inside a divergent region: " + code))
-                    exec_masked = True
-            elif exec_masked and (op.startswith("s_cbranch") or op in ("s_branch", "s_endpgm", "s_barrier")):
-                hazards.append((kernel, ln, "EXEC still holds a bitmap at: " + code))
-        elif "saveexec" in op:
-            divergent += 1
-        elif op == "s_or_b64" and args[:2] == ["exec", "exec"] and divergent:
-            divergent -= 1
-        if op in ("s_branch", "s_endpgm", "s_setpc_b64") and not in_asm:
-            # control does not fall through: what follows is reached by jumps only, from places whose own waits were walked
-            # where they stand (the compiler's out-of-line blocks load kernel arguments and jump back to the wait)
-            pending = set()
-            continue
-        if op.startswith("s_waitcnt"):
-            if "lgkmcnt(0)" in code or re.fullmatch(r"s_waitcnt\s+0", code):
-                pending, waits = set(), waits + 1
-            continue
-        if op.startswith("s_load_dword") or op.startswith("s_buffer_load"):
-            base = set().union(*[sgprs(a) for a in args[1:]])
-            if base & pending:
-                hazards.append((kernel, ln, code))
-            pending |= sgprs(args[0])
-            loads += 1
-            continue
-        if pending:
-            used = set().union(*[sgprs(a) for a in args]) if args else set()
-            if used & pending:
-                hazards.append((kernel, ln, code))
-    return hazards, loads, waits, exec_stretches
+        if cur is not None:
+            cur.append((ln, code, in_asm))
+    return out
+
+
+def _smem_step(code, pending, report):
+    """Transfer function of check (1) for one instruction: returns the pending set behind it; report(code) on a hazard."""
+    parts = code.replace(",", " ").split()
+    op, args = parts[0], parts[1:]
+    if op.startswith("s_waitcnt"):
+        if "lgkmcnt(0)" in code or re.fullmatch(r"s_waitcnt\s+0", code):
+            return set()
+        return pending
+    if op.startswith("s_load_dword") or op.startswith("s_buffer_load"):
+        base = set().union(*[sgprs(x) for x in args[1:]]) if len(args) > 1 else set()
+        if base & pending:
+            report(code)
+        return pending | sgprs(args[0])
+    if pending:
+        used = set().union(*[sgprs(x) for x in args]) if args else set()
+        if used & pending:
+            report(code)
+    return pending
+
+
+def check(asm_text):
+    """(1) control-flow aware: basic blocks from the .LBB labels and the s_branch / s_cbranch targets, the pending-SGPR set propagated
+    forward with a UNION at joins until nothing changes (a wait inside a conditionally skipped block does not clear the set of the path
+    around it).  (2) EXEC discipline and (3) the sink register of the prefetch loads walk the text in order (asm statements are
+    straight-line code)."""
+    hazards = []
+    loads = waits = exec_stretches = sinks = 0
+    for kernel, ins in _kernels(asm_text):
+        # ---- basic blocks
+        leaders = {0}
+        label_at = {}
+        for i, (ln, code, _) in enumerate(ins):
+            if code.startswith(".LBB") and code.endswith(":"):
+                label_at[code[:-1]] = i
+                leaders.add(i)
+            op = code.split()[0]
+            if (op.startswith("s_cbranch") or op in ("s_branch", "s_endpgm", "s_setpc_b64")) and i + 1 < len(ins):
+                leaders.add(i + 1)
+        starts = sorted(leaders)
+        block_of = {}
+        for bi, st in enumerate(starts):
+            for i in range(st, starts[bi + 1] if bi + 1 < len(starts) else len(ins)):
+                block_of[i] = bi
+        succ = [[] for _ in starts]
+        for bi, st in enumerate(starts):
+            en = (starts[bi + 1] if bi + 1 < len(starts) else len(ins)) - 1
+            if en < st:
+                continue
+            code = ins[en][1]
+            parts = code.replace(",", " ").split()
+            op = parts[0]
+            fall = op not in ("s_branch", "s_endpgm", "s_setpc_b64")
+            if op.startswith("s_cbranch") or op == "s_branch":
+                tgt = parts[-1]
+                if tgt in label_at:
+                    succ[bi].append(block_of[label_at[tgt]])
+            if fall and bi + 1 < len(starts):
+                succ[bi].append(bi + 1)
+        # ---- forward dataflow of the pending set
+        inset = [set() for _ in starts]
+        outset = [None for _ in starts]
+        work = list(range(len(starts)))
+        while work:
+            bi = work.pop(0)
+            pend = set(inset[bi])
+            st = starts[bi]
+            en = starts[bi + 1] if bi + 1 < len(starts) else len(ins)
+            for i in range(st, en):
+                code = ins[i][1]
+                if code.startswith(".LBB") or code.startswith("#"):
+                    continue
+                pend = _smem_step(code, pend, lambda c: None)
+            if outset[bi] is None or pend != outset[bi]:
+                outset[bi] = pend
+                for sb in succ[bi]:
+                    if not pend <= inset[sb]:
+                        inset[sb] |= pend
+                        if sb not in work:
+                            work.append(sb)
+                    elif outset[sb] is None and sb not in work:
+                        work.append(sb)
+        # ---- report with the converged sets
+        for bi, st in enumerate(starts):
+            pend = set(inset[bi])
+            en = starts[bi + 1] if bi + 1 < len(starts) else len(ins)
+            for i in range(st, en):
+                ln, code, _ = ins[i]
+                if code.startswith(".LBB") or code.startswith("#"):
+                    continue
+                op = code.split()[0]
+                if op.startswith("s_load_dword") or op.startswith("s_buffer_load"):
+                    loads += 1
+                if op.startswith("s_waitcnt") and ("lgkmcnt(0)" in code or re.fullmatch(r"s_waitcnt\s+0", code)):
+                    waits += 1
+                pend = _smem_step(code, pend, lambda c, ln=ln: hazards.append((kernel, ln, c)))
+        # ---- (2) EXEC discipline, (3) sink register: text order
+        in_asm = exec_masked = False
+        divergent = 0
+        sink_regs, sink_lines, vwrites, sink_end = set(), set(), [], None
+        for ln, code, _ in ins:
+            if code == "#SINKEND":
+                sink_end = ln
+                continue
+            if code == "#ASMSTART":
+                in_asm = True
+                continue
+            if code == "#ASMEND":
+                if exec_masked:
+                    hazards.append((kernel, ln, "asm statement ends with a bitmap in EXEC"))
+                in_asm = exec_masked = False
+                continue
+            if code.startswith(".LBB"):
+                continue
+            parts = code.replace(",", " ").split()
+            op, args = parts[0], parts[1:]
+            if in_asm:
+                if op == "s_mov_b64" and args and args[0] == "exec":
+                    if args[1] == "-1":
+                        exec_stretches += exec_masked
+                        exec_masked = False
+                    else:
+                        if divergent:
+                            hazards.append((kernel, ln, "EXEC-masking asm statement inside a divergent region: " + code))
+                        exec_masked = True
+                elif exec_masked and (op.startswith("s_cbranch") or op in ("s_branch", "s_endpgm", "s_barrier")):
+                    hazards.append((kernel, ln, "EXEC still holds a bitmap at: " + code))
+                if op == "global_load_dword" and len(args) >= 3 and sgprs(args[2]):   # pf_at(): the sink load
+                    sink_regs |= vgprs(args[0])
+                    sink_lines.add(ln)
+                    sinks += 1
+            elif "saveexec" in op:
+                divergent += 1
+            elif op == "s_or_b64" and args[:2] == ["exec", "exec"] and divergent:
+                divergent -= 1
+            # destination registers of vector instructions / loads (first operand; stores and compares write no VGPR)
+            if args and (op.startswith("v_") or op.startswith("ds_read") or op.startswith("buffer_load") or op.startswith("global_load") or
+                         op.startswith("flat_load") or op.startswith("scratch_load")) and not op.startswith("v_cmp") and not op.startswith("v_writelane_b32_dummy"):
+                vwrites.append((ln, vgprs(args[0]), code))
+        # ---- (4) a vector-memory instruction inside an asm statement that reads an SGPR a VECTOR instruction wrote fewer than five
+        # wait states earlier (v_readlane of a spilled pointer in front of pf_at's global_load: the compiler's hazard recogniser
+        # does not look inside asm statements)
+        hist = []   # (code, in_asm) in text order, the kernel's straight-line view
+        for ln, code, ia in ins:
+            if code.startswith("#") or code.startswith(".LBB"):
+                if code.startswith(".LBB"):
+                    hist = []       # (a label: predecessors unknown here; the compiler-made code in front of a join is hazard-free by itself)
+                continue
+            parts = code.replace(",", " ").split()
+            op, args = parts[0], parts[1:]
+            if ia and (op.startswith("global_") or op.startswith("buffer_") or op.startswith("flat_")):
+                need = set().union(*[sgprs(x) for x in args]) if args else set()
+                states = 0
+                for pcode in reversed(hist):
+                    pparts = pcode.replace(",", " ").split()
+                    pop, pargs = pparts[0], pparts[1:]
+                    if pop.startswith("v_") and pargs and sgprs(pargs[0]) & need:
+                        hazards.append((kernel, ln, f"{code}  <- {pcode} ({states} wait states)"))
+                        break
+                    states += int(pargs[0]) + 1 if pop == "s_nop" and pargs else 1
+                    if states >= 5:
+                        break
+            hist.append(code)
+            if len(hist) > 12:
+                hist.pop(0)
+        if len(sink_regs) > 1:
+            hazards.append((kernel, min(sink_lines), f"prefetch sink loads name more than one register: v{sorted(sink_regs)}"))
+        # between the first sink load and the end of the sink's life (the `; sink_end` marker of the kernel's last asm statement on it; text
+        # order: the prologue and the window workgroups' path, which hold no sink load, lie outside) nothing else may write the register
+        for ln, regs, code in vwrites:
+            if sink_lines and ln not in sink_lines and regs & sink_regs and min(sink_lines) < ln < (sink_end or 1 << 60):
+                hazards.append((kernel, ln, "the prefetch sink register is written by: " + code))
+    return hazards, loads, waits, exec_stretches, sinks
 
 
 def main():
+    if len(sys.argv) > 1:
+        hazards, loads, waits, stretches, sinks = check(open(sys.argv[1]).read())
+        print(f"scalar loads: {loads}, draining waits: {waits}, EXEC-masked stretches restored: {stretches}, prefetch sink loads: {sinks}, hazards: {len(hazards)}")
+        for k, ln, code in hazards[:20]:
+            print(f"  {k}: line {ln}: {code}")
+        return 1 if hazards else 0
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "spmv.s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16", "--cuda-device-only",
                                "-S", "-I" + os.path.join(ROOT, "include"), SRC, "-o", out], stderr=subprocess.DEVNULL)
-        hazards, loads, waits, stretches = check(open(out).read())
-    print(f"scalar loads: {loads}, draining waits: {waits}, EXEC-masked stretches restored: {stretches}, hazards: {len(hazards)}")
+        hazards, loads, waits, stretches, sinks = check(open(out).read())
+    print(f"scalar loads: {loads}, draining waits: {waits}, EXEC-masked stretches restored: {stretches}, prefetch sink loads: {sinks}, hazards: {len(hazards)}")
     for k, ln, code in hazards[:20]:
         print(f"  {k}: line {ln}: {code}")
     return 1 if hazards else 0

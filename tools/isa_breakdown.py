@@ -17,7 +17,7 @@ import sys
 CLASSES = [
     ("v_mbcnt", r"v_mbcnt_"),
     ("v_lshl_add_u32 (gather address)", r"v_lshl_add_u32"),
-    ("v_mov_b32 .., 0 (zero)", r"v_mov_b32_e32 v\d+, 0$"),
+    ("v_mov_b32 .., 0 (zero)", r"v_mov_b32(_e32)? v\d+, 0$"),
     ("v_or_b32", r"v_or_b32"),
     ("v_dot2_f32_f16", r"v_dot2_f32_f16"),
     ("v_fma_mix", r"v_fma_mix"),
@@ -65,11 +65,34 @@ def main():
     ap.add_argument("asm")
     ap.add_argument("kernel", help="substring of the mangled kernel name")
     ap.add_argument("--tiles", type=int, default=128, help="tiles one wave works through per trip of the block loop")
+    ap.add_argument("--one-body", action="store_true", help="the loop holds ONE body for both waves of a pair (decode_onepass_sb_kernel): every "
+                    "block of the loop is on the path; without it the second and fourth largest blocks (the other parity's phases) are left out")
+    ap.add_argument("--markers", action="store_true", help="count what lies between the `; sb_trips_begin` and `; sb_trips_end` comments of the "
+                    "kernel's text (decode_onepass_sb_kernel: with one trip per pair there is no loop to find); implies --one-body")
     a = ap.parse_args()
     lines = open(a.asm).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S*" + re.escape(a.kernel) + r"\S*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start + 1:end]
+    if a.markers:
+        b0 = next(i for i, l in enumerate(body) if "sb_trips_begin" in l)
+        b1 = next(i for i, l in enumerate(body) if "sb_trips_end" in l)
+        tot = collections.Counter()
+        for l in body[b0:b1]:
+            t = l.strip()
+            if not t or t.startswith(";") or t.startswith(".") or re.match(r"^\.?LBB", t):
+                continue
+            t = t.split(";")[0].strip()
+            if t:
+                tot[classify(t)] += 1
+        v = sum(k for (c, _), k in tot.items() if c == "V")
+        print(f"kernel {a.kernel}: between the trip markers {sum(tot.values())} instructions, {v} vector = {v / a.tiles:.2f} per tile ({a.tiles} tiles per wave and trip)")
+        for (c, name), k in sorted(tot.items(), key=lambda x: (x[0][0] != "V", -x[1])):
+            print(f"   {'VALU' if c == 'V' else '    '}  {name:48s} {k:5d}   {k / a.tiles:6.3f} per tile")
+        loopcls = {"v_mbcnt", "v_lshl_add_u32 (gather address)", "v_mov_b32 .., 0 (zero)", "v_or_b32", "v_dot2_f32_f16", "v_fma_mix", "v_mfma"}
+        inner = sum(k for (c, name), k in tot.items() if c == "V" and name in loopcls)
+        print(f"\nstep loop (rank, address, zero, or, FMA): {inner} = {inner / a.tiles:.2f} per tile;  everything else: {v - inner} = {(v - inner) / a.tiles:.2f} per tile")
+        return
     # basic blocks by label
     blocks = collections.OrderedDict()
     cur = "entry"
@@ -107,8 +130,11 @@ def main():
     big = sorted(big, key=lambda n: pos[n])
     print(f"kernel {a.kernel}: {sum(len(v) for v in blocks.values())} instructions, block loop = {names[lo]}..{names[hi]} "
           f"({sum(sizes.values())} instructions in the loop's text)")
-    print("phase bodies (text order: key even, key odd, value even, value odd):", ", ".join(f"{n}={sizes[n]}" for n in big))
-    path = [n for n in inloop if n not in (big[1], big[3])]
+    print("phase bodies (text order):", ", ".join(f"{n}={sizes[n]}" for n in big if n))
+    path = list(inloop) if a.one_body else [n for n in inloop if n not in (big[1], big[3])]
+    if a.one_body:
+        big = sorted(sorted(inloop, key=lambda n: -sizes[n])[:2], key=lambda n: pos[n])   # key phases (A, B), value phases (A, B)
+        big = [big[0], None, big[1], None]
     tot = collections.Counter()
     per_region = collections.OrderedDict()
     for n in path:

@@ -4,7 +4,7 @@
     python tools/quick.py --cfg c3 c5 --set valu dot2 mfma valu:lean=0 valu:onepass=0 dot2:tbw=2
 
 A setting is engine[:key=value...] with engine in valu | dot2 | mfma and keys onepass (0 | 1 | 2), lean (0 | 1), tbw, wgs,
-winlast, pslab.
+winlast, pslab, sb (1: round 5's super-block pair kernel, 0: round 4's pair kernel).
 Per setting: self-check against the two reference entry points, then the step replayed as a graph (tokens/s) and the
 kernels' own durations.  One line per (config, setting)."""
 import argparse
@@ -46,6 +46,7 @@ def main():
             _lib.check(lib.mustafar_tune(2, int(kv.get("wgs", 0))), "wgs")
             _lib.check(lib.mustafar_tune(3, int(kv.get("winlast", 1))), "winlast")
             _lib.check(lib.mustafar_tune(4, int(kv.get("pslab", 0))), "pslab")
+            _lib.check(lib.mustafar_tune(8, int(kv.get("sb", 1))), "sb")
             ex = w.self_check()
             dt, (ku, vu, n) = w.timed_graph(a.steps, 3)
             rl = w.roofline(ku, vu, n, traffic_file=False)
