@@ -469,7 +469,7 @@ class Workload:
             # which one-pass kernel ran (the last fused call on this thread was the eager pass that took these timestamps)
             ch = self.lib.mustafar_last_decode_choice()
             eng, form = ch & 15, (ch >> 8) & 15
-            dom = {2: f"decode_onepass_leanpair_kernel<{eng}>", 1: f"decode_onepass_lean_kernel<{eng}>"}.get(
+            dom = {3: f"decode_onepass_sb_kernel<{eng}>", 2: f"decode_onepass_leanpair_kernel<{eng}>", 1: f"decode_onepass_lean_kernel<{eng}>"}.get(
                 form, "decode_onepass_kernel<G, matrix pipe>" if eng == 1 else "decode_onepass_kernel<G, v_fma_mix, pair>")
             dom_us, oth_us = key_us, None
             dom_bytes = self.alg_key + self.alg_val

@@ -198,9 +198,16 @@ typedef h16 h16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
+// MUSTAFAR_META_TOUCH (experiment, off): see metab_issue_touch_at
+#ifndef MUSTAFAR_META_TOUCH
+#define MUSTAFAR_META_TOUCH 0
+#endif
 struct MetaB {         // tile metadata of one step (8 tiles) -- all SGPRs
     u32x16 bm;         // 8 bitmaps (lo, hi dwords)
     u32x8 ix;          // 8 stream offsets (half2 units)
+#if MUSTAFAR_META_TOUCH
+    uint32_t t0 = 0, t1 = 0;   // landing registers of metab_issue_touch_at's two touches (never read; they stay allocated until the wait)
+#endif
 };
 
 // MUSTAFAR_META_EARLY (default): the NEXT step's bitmaps and offsets are requested in front of this step's gathers, so that the one
@@ -240,12 +247,22 @@ __device__ __forceinline__ void metab_issue(MetaB& m, const uint64_t* __restrict
                  : "s"(bmp), "s"(idx), "i"(S * 64), "i"(S * 32));
 }
 #ifdef MUSTAFAR_PROBE_NOMETAWAIT   // timing-only build: the next step does not wait for its metadata; results wrong (LDS reads out of range return 0)
-__device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_nop 0" : "+s"(m.bm), "+s"(m.ix)); }
+#if MUSTAFAR_META_TOUCH
+#define MUSTAFAR_MOPS_T , "+s"(m.t0), "+s"(m.t1)
 #else
-__device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix)); }
+#define MUSTAFAR_MOPS_T
+#endif
+__device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_nop 0" : "+s"(m.bm), "+s"(m.ix) MUSTAFAR_MOPS_T); }
+#else
+#if MUSTAFAR_META_TOUCH
+#define MUSTAFAR_MOPS_T , "+s"(m.t0), "+s"(m.t1)
+#else
+#define MUSTAFAR_MOPS_T
+#endif
+__device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix) MUSTAFAR_MOPS_T); }
 #endif
 // Ordering point without an instruction: legal right after a wait that already drained the counter.
-__device__ __forceinline__ void metab_ready(MetaB& m) { asm volatile("" : "+s"(m.bm), "+s"(m.ix)); }
+__device__ __forceinline__ void metab_ready(MetaB& m) { asm volatile("" : "+s"(m.bm), "+s"(m.ix) MUSTAFAR_MOPS_T); }
 
 // Coefficients of step S: per head 8 halfs (4 dwords).  ONE buffer: the loads of step S are issued after the FMAs of
 // step S - 1 have issued and land during the gather phase of step S (whose wait drains them too) -- a second buffer
@@ -1942,6 +1959,28 @@ __device__ __forceinline__ void metab_issue_at(MetaB& m, const uint64_t* __restr
                  : "s"(bmp), "s"(idx), "i"(TOFF * 8), "i"(TOFF * 4));
 #endif
 }
+// The same with a TOUCH of the metadata two steps ahead (TT = its tile offset, < 0: none): one dword of the bitmap line and one of the
+// offset line that the request AFTER this one will want -- they ride in this request's wait (same issue time, same L2 latency) and pull
+// the 64-byte lines into the scalar cache, so that from a chunk's second step on the 96-byte requests are scalar-cache hits instead of one
+// L2 round trip per step (probe build with every wave on the same hot lines: c3 40.7 -> 36.8 us, c5 128.5 -> 117.5: the bound of this).
+// MEASURED SLOWER (round 5, same box, kernel us, without / with: c3 42.0 / 43.2, c4 67.6 / 69.8, c5 128.4 / 133.4, c2 15.4 / 15.4): the
+// touches are scalar-cache misses themselves, every wait is a full drain, and 64 waves share a 16 KB scalar cache.  Off
+// (MUSTAFAR_META_TOUCH = 0); kept as an experiment knob.
+template <int TOFF, int TT>
+__device__ __forceinline__ void metab_issue_touch_at(MetaB& m, const uint64_t* __restrict__ bmp, const uint32_t* __restrict__ idx)
+{
+    if constexpr (TT < 0 || !MUSTAFAR_META_TOUCH) {
+        metab_issue_at<TOFF>(m, bmp, idx);
+    } else {
+#if defined(MUSTAFAR_PROBE_HOTMETA) || !MUSTAFAR_META_TOUCH
+        metab_issue_at<TOFF>(m, bmp, idx);
+#else
+        asm volatile("s_load_dwordx16 %0, %4, %6\n\ts_load_dwordx8 %1, %5, %7\n\ts_load_dword %2, %4, %8\n\ts_load_dword %3, %5, %9"
+                     : "=&s"(m.bm), "=&s"(m.ix), "=&s"(m.t0), "=&s"(m.t1)
+                     : "s"(bmp), "s"(idx), "i"(TOFF * 8), "i"(TOFF * 4), "i"(TT * 8), "i"(TT * 4));
+#endif
+    }
+}
 // coefficients of one step for the four heads: 16 bytes each at base + OFF + h * HS
 template <int OFF, int HS>
 __device__ __forceinline__ void coef4_issue_at(u32x4 (&c)[4], const void* __restrict__ base)
@@ -2134,34 +2173,38 @@ __device__ __forceinline__ uint32_t prefetch_meta_all(const uint64_t* __restrict
 // One staged chunk (32 tiles) of the lean kernel; the step schedule is chunk32's.
 //   bmp_t / idx_t : the BLOCK's bitmaps / offsets (the chunk starts TOFF tiles in);  cbase + COFF + h * HS : the chunk's first
 //   coefficient of head h
-template <int ENG, int TOFF, int COFF, int HS, int G = 4, class CB = const void*>   // CB: const void* (rows HS bytes apart) or CoefPtrs<G>
+template <int ENG, int TOFF, int COFF, int HS, int G = 4, class CB = const void*, int NTOFF = -2>   // CB: const void* (rows HS bytes apart) or CoefPtrs<G>;
+                                           // NTOFF: tile offset of the chunk the wave works on NEXT (-1: none; -2: no touches at all, the round-4 callers)
 __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restrict__ bmp_t, const uint32_t* __restrict__ idx_t,
                                            const CB& cbase, float (&acc)[G])
 {
+    // tile offset of the metadata the request of step S + 1 touches -- that of step S + 2, the next chunk's first step behind this chunk's last
+    // (metab_issue_touch_at) -- or -1
+#define MUSTAFAR_TT(S) (NTOFF == -2 ? -1 : ((S) + 2 < 4 ? TOFF + 8 * ((S) + 2) : (NTOFF >= 0 ? NTOFF + 8 * ((S) + 2 - 4) : -1)))
     static_assert(G == 4 || ENG == 0, "dot2 pairs four heads' coefficients; G < 4 runs v_fma_mix");
     // (with the coefficients in scalar registers as well, an early request leaves the loop 140+ registers short of the 78 a wave of
     // this launch has, and the compiler then spills registers that loads are still writing: tools/check_smem_hazards.py)
     constexpr bool kEarly = MUSTAFAR_META_EARLY > 1;
     MetaB cur, nxt;
     u32x4 c[G];
-    metab_issue_at<TOFF>(cur, bmp_t, idx_t);
+    metab_issue_touch_at<TOFF, (NTOFF == -2 ? -1 : TOFF + 8)>(cur, bmp_t, idx_t);
     coef_issue_at<G, COFF, HS>(c, cbase);
     metab_wait(cur);
 #define MUSTAFAR_STEP(S)                                        \
-    if constexpr (kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t); \
+    if constexpr (kEarly) metab_issue_touch_at<TOFF + 8 * (S + 1), MUSTAFAR_TT(S)>(nxt, bmp_t, idx_t); \
     if constexpr (ENG == 2) {                                   \
         if constexpr (G == 4) {                                 \
             Gathered2 g;                                        \
             gather8_d2(cur, adj, g);                            \
             gather2_wait(g, c);                                 \
-            if constexpr (!kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
+            if constexpr (!kEarly) metab_issue_touch_at<TOFF + 8 * (S + 1), MUSTAFAR_TT(S)>(nxt, bmp_t, idx_t);  \
             fma8_d2(c, g, acc);                                 \
         }                                                       \
     } else {                                                    \
         Gathered g;                                             \
         gather8(cur, adj, g);                                   \
         gather_wait<G>(g, c);                                   \
-        if constexpr (!kEarly) metab_issue_at<TOFF + 8 * (S + 1)>(nxt, bmp_t, idx_t);  \
+        if constexpr (!kEarly) metab_issue_touch_at<TOFF + 8 * (S + 1), MUSTAFAR_TT(S)>(nxt, bmp_t, idx_t);  \
         fma8<G>(c, g, acc);                                     \
     }                                                           \
     if constexpr (kEarly) metab_ready(nxt); else metab_wait(nxt); \
@@ -2182,6 +2225,7 @@ __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restr
         gather_wait<G>(g, c);
         fma8<G>(c, g, acc);
     }
+#undef MUSTAFAR_TT
 }
 
 // The 128 tiles of one 64-token block against the coefficients at cbase (four rows HS bytes apart).
@@ -2260,6 +2304,74 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
         if (VAL && CB + CN > 2) {
 #pragma unroll
             for (int h = 0; h < G; h++) accB[h] = mB[h];
+        }
+    }
+}
+
+// TWO consecutive blocks (A and B = A + 1) of a wave's half -- its 64 tiles of each -- as ONE pipeline of four chunks (A0, A1, B0, B1): the
+// first chunk of B is in flight while the last chunk of A is worked on, so that a pair of phases starts with ONE exposed stream latency
+// instead of two (round 5, decode_onepass_sb_kernel).  bmp_t / idx_t / cbase: block A's (block B's tiles lie 128 tiles behind; its e
+// segments -- VAL -- 512 bytes behind, its q rows are the same); bnd: A's three bounds in lanes 0..2, B's in lanes 8..10.
+//   mid1: called in front of chunk A1, mid3 in front of chunk B1 (the caller's requests for what comes next).
+template <int ENG, int HS, bool VAL, int G, class MID1, class MID3>
+__device__ __forceinline__ void lean_pair_phase(unsigned char* lds, uint32_t lds_addr, const uint64_t* __restrict__ bmp_t,
+                                                const uint32_t* __restrict__ idx_t, const unsigned char* __restrict__ nz_h,
+                                                const void* cbase, uint32_t bnd, int lane, float (&accA)[G], float (&accB)[G]
+#ifdef MUSTAFAR_WAVE_TRACE
+                                                , PhaseTrace& phase_trace_
+#endif
+                                                , uint32_t ctab_lane, const MID1& mid1, const MID3& mid3)
+{
+    constexpr int kE = VAL ? 4 * 64 * 2 : 0;   // coefficient offset of block B (bytes): the next block's e segments; the same q rows
+    f32x4 mA = {0.f, 0.f, 0.f, 0.f}, mB = {0.f, 0.f, 0.f, 0.f};   // (ENG == 1 only)
+    if constexpr (ENG == 1) {
+        static_assert(ENG != 1 || G == 4, "the matrix-pipe engine multiplies four heads at a time");
+#pragma unroll
+        for (int h = 0; h < G; h++) { mA[h] = accA[h]; mB[h] = VAL ? 0.f : accB[h]; }   // (VAL: both blocks add into accA's registers)
+    }
+    uint32_t i0 = bnd_get(bnd, 0);
+    const uint32_t len0 = 4u * (bnd_get(bnd, 1) - i0);
+    Stage st = stage_issue<ENG == 1>(nz_h + 4ull * i0, len0, lane);
+    stage_commit<ENG == 1>(lds, st, lane, len0);
+#ifdef MUSTAFAR_WAVE_TRACE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    MUSTAFAR_PTRACE_STAMP(VAL ? 4 : 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t n0 = 0, nlen = 0;
+        if (k < 3) {
+            const int nl = ((k + 1) >> 1) * 8 + ((k + 1) & 1);   // lane of the next chunk's lower bound: 1, 8, 9
+            n0 = bnd_get(bnd, nl);
+            nlen = 4u * (bnd_get(bnd, nl + 1) - n0);
+            st = stage_issue<ENG == 1>(nz_h + 4ull * n0, nlen, lane);
+        }
+        if (k == 1) mid1();
+        if (k == 3) mid3();
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t adj = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
+        if constexpr (ENG == 1) {
+            if (k == 0)      chunk32_mfma_at<0, 0>(adj, bmp_t, idx_t, ctab_lane, mA);
+            else if (k == 1) chunk32_mfma_at<32, 64>(adj, bmp_t, idx_t, ctab_lane, mA);
+            else if (k == 2) chunk32_mfma_at<128, 0>(adj, bmp_t, idx_t, ctab_lane + (VAL ? 4 * kValTabStride : 0), VAL ? mA : mB);
+            else             chunk32_mfma_at<160, 64>(adj, bmp_t, idx_t, ctab_lane + (VAL ? 4 * kValTabStride : 0), VAL ? mA : mB);
+        } else {
+            if (k == 0)      chunk32_at<ENG, 0, 0, HS, G, const void*, 32>(adj, bmp_t, idx_t, cbase, accA);
+            else if (k == 1) chunk32_at<ENG, 32, 64, HS, G, const void*, 128>(adj, bmp_t, idx_t, cbase, accA);
+            else if (k == 2) chunk32_at<ENG, 128, kE, HS, G, const void*, 160>(adj, bmp_t, idx_t, cbase, accB);
+            else             chunk32_at<ENG, 160, kE + 64, HS, G, const void*, -1>(adj, bmp_t, idx_t, cbase, accB);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (k < 3) {
+            stage_commit<ENG == 1>(lds, st, lane, nlen);
+            i0 = n0;
+        }
+    }
+    if constexpr (ENG == 1) {
+#pragma unroll
+        for (int h = 0; h < G; h++) {
+            accA[h] = mA[h];
+            if (!VAL) accB[h] = mB[h];
         }
     }
 }
@@ -2693,8 +2805,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
 //   * MASK is a template parameter (the unmasked launch carries no mask arithmetic).
 // Same grid, slabs and window workgroups as decode_onepass_leanpair_kernel: a drop-in for it (`mustafar_tune(8, 0)` selects the old kernel).
 #ifndef MUSTAFAR_SB_PRIO
-#define MUSTAFAR_SB_PRIO 2   // s_setprio 1 from the start of a trip to: 1 = the end of its key phases, 2 = the end of its softmax step, 3 = the end of
-                             // its first value phase; 0 = never raised (experiment knob: tools/build_variant.sh)
+#define MUSTAFAR_SB_PRIO 3   // s_setprio 1 from the start of a trip to: 1 = the end of its key phases, 2 = the end of its softmax step, 3 = the last chunk of
+                             // its value phases (c3, kernel us: 42.6 / 42.3 / 42.0 / 40.8 for 0 / 1 / 2 / 3); 0 = never raised (experiment knob: tools/build_variant.sh)
 #endif
 template <int W>
 struct FVec;
@@ -2884,19 +2996,19 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
                 mkA = mrow[tAc * 64 + lane];
                 if (actB) mkB = mrow[tBc * 64 + lane];
             }
-            auto reqVA = [&]() {
+            auto reqVA = [&]() {   // the value side's bounds (both blocks: they are consumed as one pipeline) and block A's metadata lines
                 bndV = ld_at(viA, off_bnd);
+                if (actB && lanesB) bndV = ld_at(viA + kTilesPerTb, off_bnd);
                 pfVA = ld_at(vbA, off_bmp);
             };
             if (actB) {
+                // both blocks as one pipeline of four chunks: B's bounds are needed while A's last chunk is worked on -- they come with A's
+                // (four bytes per lane); B's metadata lines are requested in front of A's last chunk
+                if (lanesB) bndK = ld_at(kiA + kTilesPerTb, off_bnd);
                 uint32_t pfKB = 0;
-                auto reqKB = [&]() {
-                    if (lanesB) bndK = ld_at(kiA + kTilesPerTb, off_bnd);
-                    pfKB = ld_at(kbA + kTilesPerTb, off_bmp);
-                };
-                lean_block_phase<ENG, kD * 2, false, 0, 2, G, const void*, 0>(lds, lds_addr, kbA, kiA, kn, qb, bndK, lane, sA, sA MUSTAFAR_PTRACE_ARG, ctab_q, reqKB);
+                auto reqKB = [&]() { pfKB = ld_at(kbA + kTilesPerTb, off_bmp); };
+                lean_pair_phase<ENG, kD * 2, false, G>(lds, lds_addr, kbA, kiA, kn, qb, bndK, lane, sA, sB MUSTAFAR_PTRACE_ARG, ctab_q, reqKB, reqVA);
                 prefetch_done(pfKA);
-                lean_block_phase<ENG, kD * 2, false, 0, 2, G, const void*, 8>(lds, lds_addr, kbA + kTilesPerTb, kiA + kTilesPerTb, kn, qb, bndK, lane, sB, sB MUSTAFAR_PTRACE_ARG, ctab_q, reqVA);
                 prefetch_done(pfKB);
             } else {
                 lean_block_phase<ENG, kD * 2, false, 0, 2, G, const void*, 0>(lds, lds_addr, kbA, kiA, kn, qb, bndK, lane, sA, sA MUSTAFAR_PTRACE_ARG, ctab_q, reqVA);
@@ -2971,15 +3083,10 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
             // (the partner read my outgoing partial scores before the barrier above; my value phase now rewrites the window)
             if (actB) {
                 uint32_t pfVB = 0;
-                auto reqVB = [&]() {
-                    if (lanesB) bndV = ld_at(viA + kTilesPerTb, off_bnd);
-                    pfVB = ld_at(vbA + kTilesPerTb, off_bmp);
-                };
-                lean_block_phase<ENG, 64 * 2, true, 0, 2, G, const void*, 0>(lds, lds_addr, vbA, viA, vn, eA, bndV, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e, reqVB);
+                auto reqVB = [&]() { pfVB = ld_at(vbA + kTilesPerTb, off_bmp); };
+                auto dropPrio = [&]() { if (MUSTAFAR_SB_PRIO == 3) __builtin_amdgcn_s_setprio(0); };   // (in front of the last chunk: the trip is nearly done)
+                lean_pair_phase<ENG, 64 * 2, true, G>(lds, lds_addr, vbA, viA, vn, eA, bndV, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e, reqVB, dropPrio);
                 prefetch_done(pfVA);
-                if (MUSTAFAR_SB_PRIO == 3) __builtin_amdgcn_s_setprio(0);
-                lean_block_phase<ENG, 64 * 2, true, 0, 2, G, const void*, 8>(lds, lds_addr, vbA + kTilesPerTb, viA + kTilesPerTb, vn, eB, bndV, lane, acc, acc MUSTAFAR_PTRACE_ARG,
-                                                                             ctab_e + 4 * kValTabStride);
                 prefetch_done(pfVB);
             } else {
                 lean_block_phase<ENG, 64 * 2, true, 0, 2, G, const void*, 0>(lds, lds_addr, vbA, viA, vn, eA, bndV, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e);
@@ -3733,7 +3840,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
 #undef MUSTAFAR_LL
             if (prof) { g_prof.onepass++; g_prof.n++; }
             onepass_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
-            t_last_choice = eng | (1 << 4) | ((lp ? 2 : 1) << 8);
+            t_last_choice = eng | (1 << 4) | ((lp ? (g_sb && per_wg <= 4 ? 3 : 2) : 1) << 8);
             return (int)hipGetLastError();
         }
         const bool pair = fma_engine() != 1 || G != 4;                      // two waves per block unless the matrix-pipe engine runs
