@@ -55,11 +55,14 @@ CONFIGS = {  # name: (label, Hq, Hkv, sparsity, L, batch)
 }
 CONFIGS["t8192"] = ("Llama-3-8B 70% T=8192 b8 [tools only]", 32, 8, 0.7, 8192 + 32, 8)
 CONFIGS["t8448"] = ("Llama-3-8B 70% T=8448 b8 [tools only]", 32, 8, 0.7, 8448 + 32, 8)
+for _t in (8704, 8960, 9216, 9728, 10240, 12288):   # (off the grid of whole rounds of workgroups: tools/quick.py, the `seq_offgrid` leg)
+    CONFIGS[f"t{_t}"] = (f"Llama-3-8B 70% T={_t} b8 [tools only]", 32, 8, 0.7, _t + 32, 8)
 CONFIGS["b1"] = ("Llama-3-8B 70% L=8192 b1 [tools only]", 32, 8, 0.7, 8192, 1)
 CONFIGS["b1l"] = ("Llama-3-8B 70% L=32768 b1 [tools only]", 32, 8, 0.7, 32768, 1)
 CONFIGS["m8"] = ("Llama-2-7B (MHA) 70% L=8192 b8 [tools only]", 32, 32, 0.7, 8192, 8)
 CONFIGS["g2"] = ("GQA-2 (32 q / 16 kv heads) 70% L=8192 b8 [tools only]", 32, 16, 0.7, 8192, 8)
 SEQ_SWEEP = ("s4", "c3", "s16", "s32")
+OFFGRID = ("t8192", "t8448", "t8704", "t8960")
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming ceiling
 D, R = 128, 32
 
@@ -243,9 +246,14 @@ class Workload:
         """Average key / value SpMV kernel duration (the kernels' own start / stop timestamps, what rocprofv3 reports) over `run`."""
         from mustafar_amd import _lib
         _lib.check(self.lib.mustafar_profile_begin(records), "mustafar_profile_begin")
+        torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
         run()
-        ku, vu, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-        _lib.check(self.lib.mustafar_profile_end(ctypes.byref(ku), ctypes.byref(vu), ctypes.byref(n)), "mustafar_profile_end")
+        torch.cuda.synchronize(self.dev)
+        self.last_profile_wall_s = time.perf_counter() - t0    # wall time of the instrumented pass itself (the kernels' durations belong to THIS execution mode)
+        ku, vu, fu, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(self.lib.mustafar_profile_end2(ctypes.byref(ku), ctypes.byref(vu), ctypes.byref(fu), ctypes.byref(n)), "mustafar_profile_end2")
+        self.last_finish_us = fu.value                          # the row kernel behind a one-pass launch (0: other structures)
         return ku.value, vu.value, n.value
 
     def self_check(self):
@@ -448,6 +456,8 @@ class Workload:
         # taken between the nodes of a replayed graph); rocprofv3 over the replays themselves agrees (profiles/)
         nprof = min(steps, 10)
         kern = self.profile(lambda: [self.one_step(state) for _ in range(nprof)], nprof * layers)
+        self.extra["eager_pass_ms_per_step"] = round(self.last_profile_wall_s / nprof * 1e3, 4)
+        self.extra["finish_kernel_us"] = round(self.last_finish_us, 2)
         self.extra["triggers_in_timed_region"] = box["triggers"]
         if box["triggers"] and hasattr(state[0][0], "consolidate") and state[0][0].extents:
             # what consolidation costs (a launch form that cannot read extents; a full table: 512 triggers): every layer's base + extents re-housed into one base
@@ -493,8 +503,14 @@ class Workload:
                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                "traffic_measured_at": measured_at, "kernel_source_tag": kernel_source_tag(),
                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_timed": n,
-               "timing_source": "kernel start/stop timestamps (hipExtLaunchKernel events) of an eager pass over the same state "
-                                "right after the timed graph replays; rocprofv3 --kernel-trace of the replays agrees (profiles/)",
+               "timing_source": "kernel start/stop timestamps (hipExtLaunchKernel events) of an EAGER pass over the same state "
+                                "right after the timed graph replays -- kernel timestamps cannot be taken between the nodes of a replayed graph; "
+                                "the replays themselves under rocprofv3 --kernel-trace: profiles/ (a few % shorter: no launch gaps)",
+               "row_kernel_us": self.extra.get("finish_kernel_us") if onepass else None,
+               "eager_pass_ms_per_step": self.extra.get("eager_pass_ms_per_step"),
+               "sum_of_kernels_ms_per_step": round(self.layers * (dom_us + (self.extra.get("finish_kernel_us") or 0.0)) * 1e-3, 4) if onepass else None,
+               "sum_check": "layers x (one-pass kernel + row kernel) <= eager_pass_ms_per_step: the two figures of one execution mode; "
+                            "ms_per_step of the line is the replayed graph (faster than the eager pass: no host launches between the kernels)",
                "frac_of_measured_stream_ceiling_6290": round(achieved / 6290.0, 4)}
         if not onepass:
             out["other"] = {"kernel": ("key" if dom.startswith("value") else "value") + "_spmv_kernel", "avg_launch_us": round(oth_us, 2),
@@ -735,6 +751,18 @@ def main():
         trig["one_graph_device_side_T"] = {"value": round(world * w.batch * nst / dt_1, 2), "unit": "tokens/s", "ms_per_step": round(dt_1 / nst * 1e3, 4),
                                            "triggers": w.extra.get("triggers_in_timed_region"), "trigger_step_ms": w.extra.get("trigger_step_ms"),
                                            "note": "the same leg with ONE captured graph: the launches are sized for a capacity and read the compressed tokens in use from a device int (T_device); no capture behind the first"}
+    # ---- a whole generate of the reference harness: 600 new tokens (mem_spd_test.py:72-74 `output_length`) from this prompt length -- three
+    # 256-token triggers at L = 8192, and two thirds of the steps at cache lengths off the grid of whole rounds of workgroups -----------------
+    gen = None
+    if use_graph and not a.no_trigger_leg:
+        ngen = 600
+        w.extra.pop("trigger_step_ms", None)
+        dt_g, _ = w.timed_graph(ngen, 1)
+        gen = {"value": round(world * w.batch * ngen / dt_g, 2), "unit": "tokens/s", "steps": ngen, "ms_per_step": round(dt_g / ngen * 1e3, 4),
+               "triggers": w.extra.get("triggers_in_timed_region"), "trigger_step_ms": w.extra.get("trigger_step_ms"),
+               "vs_headline": round((world * w.batch * ngen / dt_g) / (world * w.batch * a.steps / dt), 4),
+               "note": "600 consecutive decode steps from the prompt length of this config (the reference harness's generate: mem_spd_test.py:72-74), "
+                       "graph of the longer cache recorded ahead of every trigger; the compressed length grows 7936 -> 8704 on the way"}
     alloc_peak = torch.cuda.max_memory_allocated(dev)
 
     # ---- the other BASELINE configs as sub-results (N = 1) -----------------------------------------------------------
@@ -765,6 +793,18 @@ def main():
                 pts[str(CONFIGS[name][4])] = run_seq_point(name, a, dev, rank, world, dist, rehearse, timer, lib)
         sweep = {"workload": "Llama-3-8B geometry (32 q / 8 kv heads, d 128, 32 layers), 70 % K / 70 % V, batch 8, fused entry point + hipGraph, default engine",
                  "points": pts}
+
+    # ---- off the grid of whole rounds of workgroups: c3's geometry at T = 8192 ... 8960 (every BASELINE point sits at T = 2^k - 256, just
+    # under one resident round; a cache that has grown by a few 256-token extents does not) -----------------------------------------
+    offgrid = None
+    if world == 1 and not a.no_seq_sweep and a.api == "fused" and not a.no_graph and a.config == "c3":
+        pts = {}
+        for name in OFFGRID:
+            p_ = run_seq_point(name, a, dev, rank, world, dist, rehearse, timer, lib)
+            pts[str(p_["compressed_tokens"])] = {k: p_[k] for k in ("compressed_tokens", "value", "unit", "ms_per_step", "steps", "kernel", "kernel_us", "roofline_frac",
+                                                                    "algorithmic_bytes_per_launch", "self_check_excess")}
+        offgrid = {"workload": "c3's geometry (Llama-3-8B, 70 % / 70 %, batch 8, 32 layers) at compressed lengths one to four 256-token triggers past T = 7936 "
+                               "(2048 + 64 k workgroups of four blocks on the chip's 2048 slots); fused entry point + hipGraph, default engine", "points": pts}
 
     if rank != 0:
         if dist is not None:
@@ -808,7 +848,7 @@ def main():
         "allocator_note": "peak of the whole bench process: the reference-layout caches kept for the other call sequences and the self-check + "
                           "the appendable (arena) copy the timed fused leg runs on + transients",
         "roofline": roofline, "roofline_fma_mix": roofline_legs.get("valu"), "roofline_mfma": roofline_mfma, "cpu_baseline": cpu,
-        "other_call_sequences": others, "fma_engine_fma_mix": engine_legs.get("valu"), "fma_engine_mfma": engine_extra, "tokens_per_sec_incl_trigger": trig, "prefill_compression": prefill, "seq_sweep": sweep, "configs": sub,
+        "other_call_sequences": others, "fma_engine_fma_mix": engine_legs.get("valu"), "fma_engine_mfma": engine_extra, "tokens_per_sec_incl_trigger": trig, "generate_600": gen, "prefill_compression": prefill, "seq_sweep": sweep, "seq_offgrid": offgrid, "configs": sub,
     }
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -311,6 +311,8 @@ int mustafar_tune(int knob, int value);
  */
 int mustafar_profile_begin(int max_records);
 int mustafar_profile_end(double* key_us_avg, double* value_us_avg, int* records);
+/* The same, and the average duration of the row kernel behind a one-pass launch (onepass_finish_kernel; 0 unless every record is one). */
+int mustafar_profile_end2(double* key_us_avg, double* value_us_avg, double* finish_us_avg, int* records);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mustafar_tune": (_i32, [_i32, _i32]),
     "mustafar_profile_begin": (_i32, [_i32]),
     "mustafar_profile_end": (_i32, [_vp, _vp, _vp]),
+    "mustafar_profile_end2": (_i32, [_vp, _vp, _vp, _vp]),
     "mustafar_prune_magnitude": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32]),
     "mustafar_compress_bitmap_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mustafar_compress_bitmap_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),

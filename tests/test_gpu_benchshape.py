@@ -36,6 +36,7 @@ CASES = {  # BASELINE.json configs[1..4]: (Hq, Hkv, sparsity, L, batch)
     "g2": (32, 16, 0.7, 4096, 4),      # GQA-2 at size: the G = 2 instantiation of the pair kernel (round 4)
     "s4": (32, 8, 0.7, 4096, 8),
     "s32": (32, 8, 0.7, 32768, 8),
+    "c3w": (32, 8, 0.7, 7936 + 32 + 255, 8),   # c3's geometry with a window one token short of the trigger (round 5: off the grid of whole rounds)
 }
 
 
@@ -169,6 +170,63 @@ def test_fused_arena_across_the_compression_trigger_at_bench_shape(name):
             # (the 256 tokens arrive as an extent behind the T base tokens, nothing re-housed: tests/test_gpu_extents.py)
             assert step == 31 and past[4] == T + 256 and past[0].total_tokens == T + 256 and past[0].tokens == T and past[1].len == 32
     assert fired == 1
+    torch.cuda.empty_cache()
+
+
+def test_c3_two_triggers_past_the_resident_round_at_T_8448():
+    """Every BASELINE point sits at T = 2^k - 256, just under ONE resident round of workgroups (c3: 1984 of the chip's 2048 slots); a
+    cache that has grown by two 256-token extents does not (T = 8448: 2112 workgroups of four blocks, 33 per head).  c3's geometry through
+    two triggers -- 7936 -> 8192 -> 8448 compressed tokens, the last 512 in two extents: the fused entry point, eager and as a replayed
+    graph, against dense attention over the pruned K / V and against the unfused call sequence at each length."""
+    from mustafar_amd import _lib
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    attn, cfg, past, ref, (Hq, Hkv, batch, T) = _setup("c3w")
+    assert T == 7936 and past[1].len == 255
+    native = MustafarAttention(MustafarConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, k_sparsity=cfg.k_sparsity,
+                                              v_sparsity=cfg.v_sparsity, residual_length=32, api="native"))
+    pend_k, pend_v = [], []
+
+    def flush():                      # (the dense reference's K / V grow by one torch.cat per check, not per step)
+        if pend_k:
+            ref.append(torch.cat(pend_k, 2), torch.cat(pend_v, 2))
+            pend_k.clear(); pend_v.clear()
+
+    fired, checks = 0, 0
+    for step in range(1 + 256 + 3):
+        q, k, v = _new(batch, Hq, Hkv)
+        pend_k.append(k); pend_v.append(v)
+        C_before = past[4]
+        out, past = attn.decode(q, k, v, past)
+        if step in (0, 1, 2, 255, 256, 257, 259):
+            flush()
+            checks += 1
+            assert excess(out, ref(q), DENSE_ULPS) <= 1.0, f"step {step} (T = {C_before}): fused vs dense attention"
+            past_n = (past[0].to_reference(), past[1].view().clone(), past[2].to_reference(), past[3].view().clone(), past[4], past[5])
+            qn, kn, vn = _new(batch, Hq, Hkv)
+            out_f, _ = attn.decode(qn, kn, vn, (past[0], past[1].clone(), past[2], past[3].clone(), past[4], past[5]))
+            out_n, _ = native.decode(qn, kn, vn, past_n)
+            assert excess(out_f, out_n, NATIVE_ULPS) <= 1.0, f"step {step}: fused vs the unfused call sequence"
+            del past_n
+        if past[4] != C_before:
+            fired += 1
+            flush()
+            ref.compress_next_256()
+            assert past[0].tokens == T and len(past[0].extents) == fired and past[0].total_tokens == T + 256 * fired
+    assert fired == 2 and past[4] == 8448 and checks == 7
+    # ---- the step at T = 8448 captured once and replayed
+    q, k, v = (torch.zeros_like(t) for t in _new(batch, Hq, Hkv))
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib = _lib.load()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out, _ = attn.decode_fused(q, k, v, past, step_counter=counter)
+        _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream().cuda_stream, counter.data_ptr(), 1), "counter")
+    for _ in range(3):
+        qn, kn, vn = _new(batch, Hq, Hkv)
+        q.copy_(qn); k.copy_(kn); v.copy_(vn)
+        ref.append(kn, vn)
+        g.replay()
+        assert excess(out, ref(qn), DENSE_ULPS) <= 1.0, "replayed step at T = 8448 vs dense attention"
     torch.cuda.empty_cache()
 
 

@@ -257,9 +257,9 @@ def check(asm_text):
     return hazards, loads, waits, exec_stretches, sinks
 
 
-def main():
-    if len(sys.argv) > 1:
-        hazards, loads, waits, stretches, sinks = check(open(sys.argv[1]).read())
+def main(asm_file=None):
+    if asm_file:
+        hazards, loads, waits, stretches, sinks = check(open(asm_file).read())
         print(f"scalar loads: {loads}, draining waits: {waits}, EXEC-masked stretches restored: {stretches}, prefetch sink loads: {sinks}, hazards: {len(hazards)}")
         for k, ln, code in hazards[:20]:
             print(f"  {k}: line {ln}: {code}")
@@ -276,4 +276,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(sys.argv[1] if len(sys.argv) > 1 else None))
