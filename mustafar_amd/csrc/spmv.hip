@@ -1513,6 +1513,10 @@ struct OneArgs {   // operands of the one-pass launch beyond the two caches (by 
     // tokens in use as a DEVICE quantity (extents only): T above is then the capacity the launch was sized for -- grid, slabs, score
     // scratch, mask columns -- and a captured graph of the launch stays valid while the cache grows up to it
     const int* t_dev = nullptr;
+    // round 5 (super-block pair form): workgroups with a linear id >= this one issue at a raised priority for their whole life -- the few
+    // workgroups of a launch's LAST, nearly empty round (a cache a trigger or two past one resident round of workgroups: T = 8448 at c3's
+    // geometry is 2112 workgroups on 2048 slots) start when the first slots free up and would otherwise crawl along at an eighth of a SIMD
+    int hi_prio_from = 0x7fffffff;
 };
 
 // Window workgroup: 64 window tokens of one head batch -> scores, softmax partial, p.V partial -> slab (S + chunk).
@@ -2966,7 +2970,9 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
     for (int h = 0; h < G; h++) acc[h] = 0.f;
 #pragma unroll
     for (int j = 0; j < HW; j++) { m_run[j] = -INFINITY; l_lane[j] = 0.f; }
-    if (MUSTAFAR_SB_PRIO) __builtin_amdgcn_s_setprio(1);
+    const bool late_round = (int)(blockIdx.y * gridDim.x + blockIdx.x) >= a.hi_prio_from;   // (workgroup-uniform)
+    if (late_round) __builtin_amdgcn_s_setprio(3);
+    else if (MUSTAFAR_SB_PRIO) __builtin_amdgcn_s_setprio(1);
     asm volatile("; sb_trips_begin");   // (markers for tools/isa_breakdown.py --markers: a comment in the ISA, no instruction)
 #pragma unroll 1
     for (int trip = 0; trip < (MULTI ? trips : 1); trip++) {
@@ -3023,7 +3029,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
             xch_out[0] = oA;
             xch_out[64] = oB;
         }
-        if (MUSTAFAR_SB_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (MUSTAFAR_SB_PRIO == 1 && !late_round) __builtin_amdgcn_s_setprio(0);
         MUSTAFAR_PTRACE_STAMP(2);
         __syncthreads();
         if (actA && has_heads) {
@@ -3066,7 +3072,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
             }
             if constexpr (ENG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my e stores have reached L2 before the pair's scalar loads
         }
-        if (MUSTAFAR_SB_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if (MUSTAFAR_SB_PRIO == 2 && !late_round) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         MUSTAFAR_PTRACE_STAMP(3);
         if (actA) {
@@ -3084,7 +3090,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
             if (actB) {
                 uint32_t pfVB = 0;
                 auto reqVB = [&]() { pfVB = ld_at(vbA + kTilesPerTb, off_bmp); };
-                auto dropPrio = [&]() { if (MUSTAFAR_SB_PRIO == 3) __builtin_amdgcn_s_setprio(0); };   // (in front of the last chunk: the trip is nearly done)
+                auto dropPrio = [&]() { if (MUSTAFAR_SB_PRIO == 3 && !late_round) __builtin_amdgcn_s_setprio(0); };   // (in front of the last chunk: the trip is nearly done)
                 lean_pair_phase<ENG, 64 * 2, true, G>(lds, lds_addr, vbA, viA, vn, eA, bndV, lane, acc, acc MUSTAFAR_PTRACE_ARG, ctab_e, reqVB, dropPrio);
                 prefetch_done(pfVA);
                 prefetch_done(pfVB);
@@ -3418,6 +3424,7 @@ inline int onepass_target_wgs(bool pair)
 // kernel with whole blocks per wave, 0 the round-2 pair form; MUSTAFAR_LEAN_TBW=n: blocks per wave (1) / block pairs per
 // workgroup (2) instead of the automatic choice (raised when the slabs would not fit).
 int g_sb = [] { const char* e = getenv("MUSTAFAR_SB"); return e ? atoi(e) != 0 : 1; }();   // round 5: the super-block pair form (mustafar_tune(8, 0): round 4's pair kernel)
+int g_late_prio = 1;    // mustafar_tune(9, 0): no raised priority for a small last round of workgroups (experiments)
 int g_pair_slabs = 0;   // pair form, mustafar_tune(4, 1): a slab per pair instead of one per workgroup (kernel 1.1 us shorter at c3, row kernel 1.5 us longer)
 // g_lean_win_last: the pair form's window workgroups sit BEHIND the SpMV rows of the grid (mustafar_tune(3, 0): in front, round 3a).
 // In front they hold 434 of the chip's 2048 workgroup slots for their ~10 us while the SpMV rows wait; behind, they fill the tail
@@ -3800,6 +3807,15 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                 a.t_dev = T_device;
             }
             const dim3 grid(S1, gy + win_rows);
+            {   // the last round of SpMV workgroups, when it is a small fraction of a resident round (8 workgroups per CU): raised priority
+                static const int slots = [] {
+                    int dev = 0, cus = 256;
+                    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                    return (cus > 0 ? cus : 256) * 8;
+                }();
+                const int64_t W = (int64_t)S1 * gy, full = W / slots * slots;
+                if (g_late_prio && full > 0 && W - full > 0 && (W - full) * 4 <= slots && !(a.win_rows > 0)) a.hi_prio_from = (int)full;
+            }
             hipEvent_t e0 = prof ? g_prof.ev[4 * g_prof.n] : nullptr, e1 = prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr;
             auto kz = static_cast<const unsigned char*>(kc.nz), vz = static_cast<const unsigned char*>(vc.nz);
 #define MUSTAFAR_LL(KERNEL)                                                                                                           \
@@ -4115,6 +4131,7 @@ int mustafar_tune(int knob, int value)
         case 6: g_key_lean = value ? 1 : 0; return 0;
         case 7: g_value_lean = value ? 1 : 0; return 0;
         case 8: g_sb = value ? 1 : 0; return 0;
+        case 9: g_late_prio = value ? 1 : 0; return 0;
         default: return MUSTAFAR_EINVAL;
     }
 }

@@ -181,7 +181,7 @@ def test_c3_two_triggers_past_the_resident_round_at_T_8448():
     from mustafar_amd import _lib
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
     attn, cfg, past, ref, (Hq, Hkv, batch, T) = _setup("c3w")
-    assert T == 7936 and past[1].len == 255
+    assert T == 7936 and past[1].len == 32 + 255   # (the window holds the residual 32 rows too: the first decode step reaches the trigger)
     native = MustafarAttention(MustafarConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, k_sparsity=cfg.k_sparsity,
                                               v_sparsity=cfg.v_sparsity, residual_length=32, api="native"))
     pend_k, pend_v = [], []
