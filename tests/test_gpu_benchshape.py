@@ -192,20 +192,21 @@ def test_c3_two_triggers_past_the_resident_round_at_T_8448():
             pend_k.clear(); pend_v.clear()
 
     fired, checks = 0, 0
+    check_at = (0, 1, 2, 255, 256, 257, 259)
     for step in range(1 + 256 + 3):
         q, k, v = _new(batch, Hq, Hkv)
         pend_k.append(k); pend_v.append(v)
         C_before = past[4]
+        past_n = None
+        if step in check_at:    # the same cache in the reference layout, taken BEFORE the step (the unfused sequence runs its own trigger, model :324-398)
+            past_n = (past[0].to_reference(), past[1].view().clone(), past[2].to_reference(), past[3].view().clone(), past[4], past[5])
         out, past = attn.decode(q, k, v, past)
-        if step in (0, 1, 2, 255, 256, 257, 259):
+        if step in check_at:
             flush()
             checks += 1
             assert excess(out, ref(q), DENSE_ULPS) <= 1.0, f"step {step} (T = {C_before}): fused vs dense attention"
-            past_n = (past[0].to_reference(), past[1].view().clone(), past[2].to_reference(), past[3].view().clone(), past[4], past[5])
-            qn, kn, vn = _new(batch, Hq, Hkv)
-            out_f, _ = attn.decode(qn, kn, vn, (past[0], past[1].clone(), past[2], past[3].clone(), past[4], past[5]))
-            out_n, _ = native.decode(qn, kn, vn, past_n)
-            assert excess(out_f, out_n, NATIVE_ULPS) <= 1.0, f"step {step}: fused vs the unfused call sequence"
+            out_n, _ = native.decode(q, k, v, past_n)
+            assert excess(out, out_n, NATIVE_ULPS) <= 1.0, f"step {step}: fused vs the unfused call sequence"
             del past_n
         if past[4] != C_before:
             fired += 1
