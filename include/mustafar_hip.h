@@ -193,6 +193,24 @@ int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_ca
  *   pass 2  mustafar_cache_append_pack_{key,value}: the new tiles' non-zeros + padding -> dst.nz at 8*nz_offset[h] halfs.
  * x fp16 [B', t, D], t % 64 == 0, old_tokens % 64 == 0.
  */
+/*
+ * The two conversion calls of the reference (kernel/compression.py:249-432: bitmaps + offsets, then the packed streams) with ONE read of
+ * the rows (round 5): the one-pass compression launch (kth = 0: already pruned) writes bitmaps, offsets and every head's stream -- into a
+ * region of worst-case size each --, the caller reads head_off (the sizes of the tensors it returns: the one host read the reference's
+ * return type asks for, compression.py:308, now BEHIND the work instead of between two passes over the rows) and
+ * mustafar_convert_pack copies the regions head behind head into the exact-size buffer, the reference's layout.
+ *   x          fp16 [B', t, 128] contiguous, t % 64 == 0           key        1: K tile geometry, 0: V
+ *   bmp / accum   i64 [B', 2t] / i32 [B', 2t + 1] out (compression.py:339)
+ *   head_off   i64 [B' + 1] out: exclusive prefix of the heads' stream lengths in halfs, [B'] = the total (compression.py:303-308)
+ *   regions    B' * t * 128 halfs of scratch (head h's stream at h * t * 128);  packed  head_off[B'] halfs
+ *   overflow_flag  device int, zeroed by the caller: bit 1 = a block gave up waiting for the lengths in front of it (see
+ *              mustafar_cache_append_kv): the results are incomplete, repeat through mustafar_compress_bitmap_* / _pack_*
+ *   scratch    mustafar_convert_scratch_bytes(B', t) bytes
+ */
+int64_t mustafar_convert_scratch_bytes(int Bp, int t);
+int mustafar_convert_onepass(void* stream, const void* x, int Bp, int t, int D, int key, int64_t* bmp, int32_t* accum, int64_t* head_off,
+                             void* regions, int32_t* overflow_flag, void* scratch);
+int mustafar_convert_pack(void* stream, const void* regions, int Bp, int t, int D, const int64_t* head_off, void* packed);
 int mustafar_cache_append_bitmap_key(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
                                      int old_tokens, int64_t* head_total);
 int mustafar_cache_append_bitmap_value(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
@@ -238,6 +256,26 @@ int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int
  */
 int mustafar_cache_rehouse(void* stream, const mustafar_cache_view* src, const mustafar_cache_view* dst, int Bp, int tokens,
                            int64_t stream_halfs);
+/*
+ * Form of the fused compression calls (mustafar_cache_append_kv, mustafar_trigger_compress_batch, mustafar_convert_onepass) from the next call
+ * on: 0 = the process default (one pass unless MUSTAFAR_COMPRESS=twopass is in the environment), 1 = one pass, 2 = the two-pass form (three
+ * launches, no wait between workgroups).  Round 5: a caller whose one-pass launch reported flag bit 1 (a block gave up waiting for the
+ * lengths in front of it) repeats the call ONCE in the two-pass form -- the raw rows are still in place, the call is idempotent -- instead
+ * of failing (cache.py; counted in cache.compress_fallbacks).  Process-wide state: set it, call, set it back.
+ * mustafar_compress_test_skip_publish (tests only): the block of this index of the NEXT one-pass launch does not publish its length, so
+ * that every block behind it times out (bit 1); -1 = off.
+ */
+int mustafar_compress_set_form(int form);
+int mustafar_compress_test_skip_publish(int block);
+/*
+ * consolidate() on the device (round 5): the `n_extents` appended extents of a cache, read through its DEVICE table of views (the table
+ * mustafar_decode_attention_extents reads), are copied behind the `base_tokens` tokens of `dst` -- a view with equally spaced stream regions
+ * that mustafar_cache_rehouse has filled with the base in the launch in front of this one.  Offsets are shifted by the head's stream
+ * length in front of each extent (model :352-360), read on the device; nothing is read on the host.  `max_extent_halfs`: an upper bound of
+ * a head's stream length in any one extent (sizes the grid; the host knows every extent's lengths).  One launch; n_extents <= 21845.
+ */
+int mustafar_cache_consolidate_extents(void* stream, const mustafar_cache_view* dst, const mustafar_cache_view* extents, int n_extents, int Bp,
+                                       int base_tokens, int64_t max_extent_halfs);
 /* Window slide of the trigger (model :392-393) in place: rows [drop, len) of every head move to the front
  * (any number of rows may stay: overlapping ranges are moved in ascending pieces). */
 int mustafar_window_drop_front(void* stream, void* k_window, void* v_window, int64_t head_stride, int Bp, int len, int drop);

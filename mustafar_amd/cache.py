@@ -87,6 +87,9 @@ class ExtentPool:
         return self._host
 
 
+compress_fallbacks = 0   # appends repeated in the two-pass form because a block of the one-pass launch gave up waiting (round 5; never seen outside tests)
+
+
 class ArenaAppendTimeout(RuntimeError):
     """The one-pass compression launch gave up waiting for a predecessor block's length (device flag bit 1).  The appended
     tokens are incomplete; MUSTAFAR_COMPRESS=twopass selects the form without that dependence."""
@@ -336,14 +339,13 @@ class CompressedArena:
             _lib.check(L.mustafar_trigger_compress_batch(st, n, items, head_stride, k0.heads, 256, 128, kth_k, kth_v, pool.nz_cap, pool.nz_cap,
                                                          pool.scratch.data_ptr()), "mustafar_trigger_compress_batch")
             host = pool.read_status()                 # ONE copy into pinned memory + ONE wait: [n pairs][flag, K totals, V totals]
-            redo = []
+            redo, timed_out = [], set()
             for i in range(n):
                 flag = int(host[i, 0]) & 0xffffffff
-                if flag & 2:
-                    raise ArenaAppendTimeout("CompressedArena: a block of the one-pass compression timed out waiting for the stream lengths in "
-                                             "front of it; nothing was appended (MUSTAFAR_COMPRESS=twopass avoids the wait)")
-                if flag:
-                    redo.append(i)
+                if flag:   # bit 0 (a head outgrew its region) or bit 1 (a block gave up waiting: round 5 repeats instead of raising): this layer
+                    redo.append(i)   # is redone on its own below -- its raw rows are still in place, nothing has slid
+                    if flag & 2:
+                        timed_out.add(i)
             keep = [i for i in range(n) if i not in redo]
             if keep:
                 sub = items if not redo else (_lib.TriggerItem * len(keep))(*[items[i] for i in keep])
@@ -355,9 +357,17 @@ class CompressedArena:
             ev.used, ev.tokens = host[i, 1 + H:1 + 2 * H].clone(), 256
             ka.extents.append(ek)
             va.extents.append(ev)
-        for i in redo:                                # bit 0: on its own, at the size the launch reported (append_window_pair's repeat)
-            (ka, va), (kr, vr) = pairs[i], rows[i]
-            CompressedArena.append_extent_pair(ka, va, kr, vr, kth_k, kth_v)
+        global compress_fallbacks
+        for i in redo:                                # bit 0: on its own, at the size the launch reported (append_window_pair's repeat);
+            (ka, va), (kr, vr) = pairs[i], rows[i]    # bit 1: on its own in the two-pass form, which has no wait between workgroups
+            if i in timed_out:
+                compress_fallbacks += 1
+                _lib.check(L.mustafar_compress_set_form(2), "mustafar_compress_set_form")
+            try:
+                CompressedArena.append_extent_pair(ka, va, kr, vr, kth_k, kth_v)
+            finally:
+                if i in timed_out:
+                    L.mustafar_compress_set_form(0)
             with torch.cuda.device(dev):
                 _lib.check(L.mustafar_window_drop_front(torch.cuda.current_stream(dev).cuda_stream, kr.data_ptr(), vr.data_ptr(), head_stride,
                                                         H, window_len, 256), "mustafar_window_drop_front")
@@ -367,10 +377,31 @@ class CompressedArena:
         self.extents = []
 
     def consolidate(self) -> "CompressedArena":
-        """One base arena holding everything (a copy of the cache; the addresses of the result are new)."""
+        """One base arena holding everything (a copy of the cache; the addresses of the result are new).  Round 5: on the device -- two
+        launches, no host read (mustafar_cache_rehouse for the base, mustafar_cache_consolidate_extents for the extents, found through
+        the device table the decode launch reads): c3, 32 layers, K and V: 162 ms through the reference layout on the host -> a few ms."""
         if not self.extents:
             return self
-        return CompressedArena.from_reference(self.to_reference(), self.which, self.total_tokens, None, self.slack)
+        n = len(self.extents)
+        if self._view.nz_head_stride == 0 or any(e._view.nz_head_stride == 0 for e in self.extents) or 3 * n > 65535 or \
+                os.environ.get("MUSTAFAR_CONSOLIDATE", "") == "host":
+            return CompressedArena.from_reference(self.to_reference(), self.which, self.total_tokens, None, self.slack)
+        base_used = self.used.clone()                                  # (host tensors; resolves asynchronous appends still in flight)
+        ext_used = [e.used for e in self.extents]
+        used = base_used.clone()
+        for u in ext_used:
+            used += u
+        total = self.total_tokens
+        new = CompressedArena(self.heads, self.which, self.device, _cap_rows(total, self.slack), _cap_nz(int(used.max()), self.slack), self.slack)
+        L = _lib.load()
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(L.mustafar_cache_rehouse(st, ctypes.byref(self._view), ctypes.byref(new._view), self.heads, self.tokens,
+                                                _round_up(int(base_used.max()) if self.tokens else 0, 8)), "mustafar_cache_rehouse")
+            _lib.check(L.mustafar_cache_consolidate_extents(st, ctypes.byref(new._view), self.ext_table.data_ptr(), n, self.heads, self.tokens,
+                                                            _round_up(max(int(u.max()) for u in ext_used), 8)), "mustafar_cache_consolidate_extents")
+        new.used, new.tokens = used, total
+        return new
 
     def _rehouse(self, cap_tokens: int, nz_cap: int):
         """Move the cache into rows of `cap_tokens` tokens and stream regions of `nz_cap` halfs (never below what it holds):
@@ -464,6 +495,7 @@ class CompressedArena:
         room for a worst-case append -- one read of the flag and the lengths, and a repeat at the measured size if a head
         outgrew its region (module docstring).  The rows must stay in place until this returns.  expect=False: the caller has
         just sized the regions itself (from_raw_pair): no room is made beforehand, an overflow is answered by the measured size."""
+        global compress_fallbacks
         heads = k_arena.heads
         if v_arena.heads != heads or k_arena.tokens != v_arena.tokens or t % 64 or t <= 0:
             raise RuntimeError("append_window_pair: K and V arenas must describe the same heads and tokens; t % 64 == 0")
@@ -498,8 +530,16 @@ class CompressedArena:
                     a._pending = (ev, t)
                     a.tokens += t
                 return
-            for attempt in range(2):
-                CompressedArena._launch_pair(k_arena, v_arena, k_rows, v_rows, t, kth_k, kth_v)
+            twopass = False
+            attempt = 0
+            while True:
+                if twopass:
+                    _lib.check(_lib.load().mustafar_compress_set_form(2), "mustafar_compress_set_form")
+                try:
+                    CompressedArena._launch_pair(k_arena, v_arena, k_rows, v_rows, t, kth_k, kth_v)
+                finally:
+                    if twopass:
+                        _lib.load().mustafar_compress_set_form(0)
                 # flag and lengths: three small copies into pinned memory, ONE wait (for the launch and the copies)
                 host = k_arena._host_landing()
                 host[0][:1].copy_(k_arena._overflow, non_blocking=True)
@@ -511,14 +551,21 @@ class CompressedArena:
                 if flag:
                     k_arena._overflow.zero_()
                 if flag & 2:
-                    raise ArenaAppendTimeout("CompressedArena: a block of the one-pass compression timed out waiting for the stream lengths in "
-                                             "front of it; nothing was appended (MUSTAFAR_COMPRESS=twopass avoids the wait)")
+                    # a block of the one-pass launch gave up waiting for the lengths in front of it (never seen; the wait relies on in-order
+                    # dispatch): the raw rows are still in place and the call is idempotent -- repeat it ONCE in the two-pass form, which has
+                    # no such wait (round 5; round 4 raised here).  A second failure is an error.
+                    if twopass:
+                        raise ArenaAppendTimeout("CompressedArena: the append failed in the two-pass form as well (flag %d); nothing was appended" % flag)
+                    compress_fallbacks += 1
+                    twopass = True
+                    continue
                 if not flag:
                     for a, tot in zip((k_arena, v_arena), totals):
                         a.used, a.tokens = tot, a.tokens + t
                     return
                 if attempt:
                     raise RuntimeError("CompressedArena: a head outgrew a stream region sized from the launch's own report: this is a bug")
+                attempt += 1
                 for a, tot in zip((k_arena, v_arena), totals):     # bit 0: the lengths the launch reported are exact: house them and repeat
                     a._make_room(t, int(tot.max()))
 

@@ -4,8 +4,10 @@ plus the magnitude prune that precedes it in the model (dh_prune_key / dh_prune_
 Same arguments, same return types as kernel/compression.py:249-339 and :341-432:
     (bitmaps int64 [B', t*D/64], accum_counts int32 [B', t*D/64 + 1], list of B' fp16 1-D tensors)
 computed by the HIP kernels in csrc/compress.hip behind the C ABI (include/mustafar_hip.h).  One small
-device->host read (B'+1 int64 offsets) sits between the two passes because the packed sizes define the
-shapes of the returned tensors; the reference needs 1 + 2B' `.item()` syncs for the same reason (:308, :333-334).
+device->host read (B'+1 int64 offsets) remains because the packed sizes define the shapes of the returned
+tensors; the reference needs 1 + 2B' `.item()` syncs for the same reason (:308, :333-334).  Since round 5 the
+rows are read ONCE (the one-pass compression launch) and the read sits behind that work, in front of a copy
+launch that packs the streams into the exact-size buffer (rounds 1-4: two passes over the rows, the read between them).
 The per-head tensors are views of one packed buffer (the reference clones each slice, :335) and remember it: they are
 `StreamPiece`s, a tensor subclass whose only behaviour is that
     torch.cat(list of all the pieces of one buffer, in order)      (model :274, :314: once per layer and decode step)
@@ -89,9 +91,23 @@ def _append_piece(old: StreamPiece, new: StreamPiece) -> torch.Tensor:
 
 
 def pieces_of(flat: torch.Tensor, offs: List[int]) -> List[torch.Tensor]:
-    """Cut a packed buffer into per-head `StreamPiece`s (offs: B' + 1 boundaries in halfs)."""
+    """Cut a packed buffer into per-head `StreamPiece`s (offs: B' + 1 boundaries in halfs).  One split call for the B' views and the
+    cheapest wrap per piece: at c3 (64 heads) this list is half of what a conversion call costs on the host (round 5: 2.3 -> 1.3 us per piece)."""
     bk = _Backing(flat, list(offs))
-    return [StreamPiece.wrap(flat[offs[b]:offs[b + 1]], bk, b) for b in range(len(offs) - 1)]
+    n = len(offs) - 1
+    if n == 0:
+        return []
+    if offs[0] != 0 or offs[-1] != flat.numel():
+        views = [flat[offs[b]:offs[b + 1]] for b in range(n)]
+    else:
+        views = flat.split([offs[b + 1] - offs[b] for b in range(n)])
+    mk = torch.Tensor._make_subclass
+    out = []
+    for b, v in enumerate(views):
+        p = mk(StreamPiece, v)
+        p._bk, p._ix = bk, b
+        out.append(p)
+    return out
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -124,14 +140,9 @@ def prune_magnitude(x: torch.Tensor, target_sparsity: float, out: torch.Tensor |
     return out.view(x.shape)
 
 
-def _convert(inputs: torch.Tensor, which: str) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
-    B, M, N = inputs.shape
-    assert inputs.is_cuda
-    assert inputs.dim() == 3
-    assert M % 64 == 0
-    if inputs.dtype != torch.float16 or N != 128:
-        raise RuntimeError("convert_*_batched expects float16 [B', t, 128]")
-    x = inputs.contiguous()
+def _convert_twopass(x: torch.Tensor, which: str) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
+    """Round 1-4 form: bitmaps + offsets (first pass over the rows), host read of the sizes, packed streams (second pass)."""
+    B, M, N = x.shape
     dev = x.device
     tiles = M * N // 64
     bitmaps = torch.empty((B, tiles), dtype=torch.int64, device=dev)
@@ -149,6 +160,54 @@ def _convert(inputs: torch.Tensor, which: str) -> Tuple[torch.Tensor, torch.Tens
                                                             accum.data_ptr(), head_off.data_ptr(),
                                                             packed.data_ptr() if offs[-1] else None)
         _lib.check(err, f"mustafar_compress_pack_{which}")
+    return bitmaps, accum, pieces_of(packed, offs)
+
+
+import os as _os
+
+# Which form a conversion call takes.  MEASURED (round 5, c3: 64 heads x 7936 tokens, wall time of a call): two passes 188 us, one pass 215 us -- the
+# call is bound by the host (B' tensor views to build for the result list), the two-pass form has LESS device work in front of the host read
+# (37 us of counting against 65 us of counting + packing) and hides its second pass behind the host's list building.  Default: two passes;
+# MUSTAFAR_CONVERT=onepass selects the one-read form (equal results, tests/test_gpu_parity.py).
+_CONVERT_ONEPASS = _os.environ.get("MUSTAFAR_CONVERT", "") == "onepass" and _os.environ.get("MUSTAFAR_COMPRESS", "") != "twopass"
+convert_fallbacks = 0   # conversions repeated through the two-pass form because a block of the one-pass launch gave up waiting (never seen)
+
+
+def _convert(inputs: torch.Tensor, which: str, onepass: bool = False) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
+    """`onepass` (or MUSTAFAR_CONVERT=onepass; round 5): ONE read of the rows.  The one-pass compression launch writes bitmaps, offsets and every head's stream (into regions of
+    worst-case size), the sizes are read on the host BEHIND that work (the reference's return type needs them: compression.py:308),
+    and one copy launch packs the regions into the exact-size buffer.  Rounds 1-4 read the rows twice with the host read in between."""
+    global convert_fallbacks
+    B, M, N = inputs.shape
+    assert inputs.is_cuda
+    assert inputs.dim() == 3
+    assert M % 64 == 0
+    if inputs.dtype != torch.float16 or N != 128:
+        raise RuntimeError("convert_*_batched expects float16 [B', t, 128]")
+    x = inputs.contiguous()
+    if not (_CONVERT_ONEPASS or onepass) or B * M * (N // 8) > 0xffffffff:
+        return _convert_twopass(x, which)
+    dev = x.device
+    tiles = M * N // 64
+    bitmaps = torch.empty((B, tiles), dtype=torch.int64, device=dev)
+    accum = torch.empty((B, tiles + 1), dtype=torch.int32, device=dev)
+    status = torch.zeros((B + 2,), dtype=torch.int64, device=dev)             # [head_off (B' + 1) | flag]
+    L = _lib.load()
+    st = _stream_ptr(dev)
+    with torch.cuda.device(dev):
+        regions = torch.empty((B * M * N,), dtype=torch.float16, device=dev)    # worst case: nothing pruned
+        scratch = torch.empty((int(L.mustafar_convert_scratch_bytes(B, M)),), dtype=torch.uint8, device=dev)
+        err = L.mustafar_convert_onepass(st, x.data_ptr(), B, M, N, 1 if which == "key" else 0, bitmaps.data_ptr(), accum.data_ptr(),
+                                         status.data_ptr(), regions.data_ptr(), status.data_ptr() + 8 * (B + 1), scratch.data_ptr())
+        _lib.check(err, "mustafar_convert_onepass")
+        host = status.cpu().tolist()     # the one host sync: sizes of the returned tensors (and the flag)
+        if host[B + 1] & 0xffffffff:
+            convert_fallbacks += 1
+            return _convert_twopass(x, which)
+        offs = host[:B + 1]
+        packed = torch.empty((offs[-1],), dtype=torch.float16, device=dev)
+        err = L.mustafar_convert_pack(st, regions.data_ptr(), B, M, N, status.data_ptr(), packed.data_ptr() if offs[-1] else None)
+        _lib.check(err, "mustafar_convert_pack")
     return bitmaps, accum, pieces_of(packed, offs)
 
 

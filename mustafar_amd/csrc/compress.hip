@@ -498,7 +498,8 @@ __device__ __forceinline__ void flush_image(const uint16_t* s_img, uint16_t* dst
     const int n16 = (int)(n_half2 >> 2);   // every tile is padded to 8 halfs = 16 bytes
     for (int p = lane; p < n16; p += 64) dst[p] = reinterpret_cast<const uint4*>(s_img)[p];
 }
-__global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(Side s0, Side s1, int ntb, uint64_t* __restrict__ gran, int32_t* __restrict__ overflow)
+__global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(Side s0, Side s1, int ntb, uint64_t* __restrict__ gran, int32_t* __restrict__ overflow,
+                                                                             int skip_publish_tb)   // (tests: this block keeps its length to itself -> its successors time out)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_img[64 * 64];   // one half of the block's stream, worst case (nothing pruned)
     const bool z = blockIdx.z != 0;
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(64, MUSTAFAR_CB_WAVES) void compress_block_kernel(S
     }
     // ---- publish the block's length
     uint64_t* g = gran + ((int64_t)(z ? gridDim.y : 0) + h) * ntb;
-    if (lane == 0) gran_publish(g + tb, total);
+    if (lane == 0 && tb != skip_publish_tb) gran_publish(g + tb, total);
     // ---- first half of the image (tiles 0..63) while the blocks in front finish counting
     if (key) {
         uint32_t run = 0;
@@ -722,12 +723,62 @@ __global__ __launch_bounds__(kThreads) void cache_rehouse_kernel(const uint64_t*
     }
 }
 
+// consolidate() on the device (round 5; cache.py): the appended 256-token extents of a cache -- listed in its DEVICE table of views --
+// copied behind the base tokens of a destination view that mustafar_cache_rehouse has just filled with the base: bitmaps as they are,
+// offsets shifted by the head's stream length in front of the extent (the model's append, llama_mustafar_kernel.py:352-360), streams
+// behind that length.  The lengths are read on the device: dst's offset entry at the end of the base (written by the re-housing launch in
+// front of this one) and every earlier extent's last offset entry.  grid: x = 16-KiB pieces of an extent's largest array, y = head,
+// z = 3 * extent + array (0 bitmaps, 1 offsets, 2 stream).
+constexpr int kExtTiles = 256 * kD / 64;   // tiles of one extent
+__global__ __launch_bounds__(kThreads) void cache_consolidate_kernel(const mustafar_cache_view* __restrict__ ext, int base_tiles, uint64_t* d_bmp,
+                                                                     uint32_t* d_idx, uint16_t* d_nz, int64_t d_bmp_stride, int64_t d_idx_stride,
+                                                                     uint32_t d_nz_stride)
+{
+    __shared__ uint32_t s_before;
+    const int h = blockIdx.y, e = blockIdx.z / 3, which = blockIdx.z % 3;
+    const mustafar_cache_view v = ext[e];
+    const int64_t tile0 = (int64_t)base_tiles + (int64_t)e * kExtTiles;
+    const uint32_t* e_idx = v.idx + (int64_t)h * v.idx_head_stride;
+    uint32_t before = 0;   // the head's stream length (half2 units) in front of this extent
+    if (which != 0) {
+        uint32_t part = 0;
+        for (int k = threadIdx.x; k < e; k += kThreads) part += ext[k].idx[(int64_t)h * ext[k].idx_head_stride + kExtTiles];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (threadIdx.x == 0) s_before = d_idx[(int64_t)h * d_idx_stride + base_tiles];
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0 && part) atomicAdd(&s_before, part);
+        __syncthreads();
+        before = s_before;
+    }
+    const int64_t piece = (int64_t)blockIdx.x * 1024 + threadIdx.x;   // 16-byte units, 4 per thread and piece
+    if (which == 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(v.bmp + (int64_t)h * v.bmp_head_stride);
+        uint4* dst = reinterpret_cast<uint4*>(d_bmp + h * d_bmp_stride + tile0);
+        const int64_t n = kExtTiles / 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int64_t p = piece + i * 256; if (p < n) dst[p] = src[p]; }
+    } else if (which == 1) {
+        uint32_t* dst = d_idx + h * d_idx_stride + tile0;
+        for (int64_t p = (int64_t)blockIdx.x * 4096 + threadIdx.x; p < (int64_t)(blockIdx.x + 1) * 4096 && p <= kExtTiles; p += kThreads) dst[p] = e_idx[p] + before;
+    } else {
+        const uint4* src = reinterpret_cast<const uint4*>(v.nz) + (int64_t)h * v.nz_head_stride;
+        uint4* dst = reinterpret_cast<uint4*>(d_nz) + (int64_t)h * d_nz_stride + before / 4;   // (lengths are multiples of four half2: 16 bytes)
+        const int64_t n = e_idx[kExtTiles] / 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int64_t p = piece + i * 256; if (p < n) dst[p] = src[p]; }
+    }
+}
+
 // MUSTAFAR_COMPRESS=twopass keeps the round-2 two-pass form of the fused calls (pass 1 + scan + pass 2); default: one pass.
+int g_compress_form = 0;       // mustafar_compress_set_form: 0 = the process default (environment), 1 = one pass, 2 = two passes
+int g_skip_publish_tb = -1;    // mustafar_compress_test_skip_publish: the NEXT one-pass launch's block of this index does not publish its length (tests)
 inline bool one_pass_compress()
 {
     static const int mode = [] { const char* e = getenv("MUSTAFAR_COMPRESS"); return (e && !strcmp(e, "twopass")) ? 0 : 1; }();
-    return mode != 0;
+    return g_compress_form ? g_compress_form == 1 : mode != 0;
 }
+inline int take_skip_publish() { const int k = g_skip_publish_tb; g_skip_publish_tb = -1; return k; }
 
 inline Rows fresh_rows(int t) { const int64_t tiles = (int64_t)t * kD / 64; return Rows{tiles, tiles + 1, 0}; }
 
@@ -810,6 +861,32 @@ int pack_common(bool key, void* stream, const void* x, int Bp, int t, int D, con
     return launch_pack(static_cast<hipStream_t>(stream), &s, 1, Bp, t, nullptr);
 }
 
+// ---- the reference's two conversion calls WITHOUT a host read (round 5: mustafar_convert_onepass) ------------------------------------
+// compress_block_kernel (one read of the rows: bitmaps, offsets, streams) writes every head's stream into a region of worst-case size;
+// then the regions are packed into the reference's layout -- head h's stream right behind head h - 1's -- by one copy launch that
+// finds its offsets on the device.  The two-pass form (tile_meta -> block_scan -> host read of the sizes -> tile_pack) stays behind
+// mustafar_compress_bitmap_* / _pack_*.
+__global__ __launch_bounds__(64) void convert_init_kernel(uint32_t* __restrict__ nz_offset, int Bp, uint32_t region_uint4)
+{
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h < Bp) nz_offset[h] = (uint32_t)h * region_uint4;
+}
+// grid: x = 16-KiB pieces of a region, y = head.  head_off: exclusive prefix of the heads' stream lengths (halfs), [B' + 1].
+__global__ __launch_bounds__(kThreads) void convert_pack_kernel(const uint16_t* __restrict__ regions, int64_t region_halfs,
+                                                                const int64_t* __restrict__ head_off, uint16_t* __restrict__ packed)
+{
+    const int h = blockIdx.y;
+    const int64_t o0 = head_off[h], len16 = (head_off[h + 1] - o0) / 8;   // 16-byte pieces (every tile's stream is padded to eight halfs)
+    const uint4* src = reinterpret_cast<const uint4*>(regions + (int64_t)h * region_halfs);
+    uint4* dst = reinterpret_cast<uint4*>(packed + o0);                    // (o0 is a multiple of 8 halfs: 16-byte aligned)
+    const int64_t p0 = (int64_t)blockIdx.x * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int64_t p = p0 + threadIdx.x + i * kThreads;
+        if (p < len16) dst[p] = src[p];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -843,6 +920,43 @@ int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int
 { return pack_common(false, stream, x, Bp, t, D, bmp, accum, head_off, nullptr, nz_flat, fresh_rows(t)); }
 
 // ---- in-place append into a cache view (model :339-390 without the re-copies) ----------------------------------------
+int64_t mustafar_convert_scratch_bytes(int Bp, int t)
+{
+    if (Bp < 1 || t < 64 || (t & 63)) return 0;
+    return (int64_t)Bp * (t / 64) * (int64_t)sizeof(uint64_t) + (((int64_t)Bp * 4 + 15) & ~(int64_t)15);
+}
+
+int mustafar_convert_onepass(void* stream, const void* x, int Bp, int t, int D, int key, int64_t* bmp, int32_t* accum, int64_t* head_off,
+                             void* regions, int32_t* overflow_flag, void* scratch)
+{
+    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || !head_off || !regions || !overflow_flag || !scratch ||
+        (int64_t)Bp * t * (kD / 8) > 0xffffffffll)   // (stream starts in 16-byte units are 32-bit, as in the format)
+        return MUSTAFAR_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ntb = t / 64;
+    const int64_t region_halfs = (int64_t)t * kD;                 // worst case: nothing pruned, every tile full
+    uint64_t* gran = static_cast<uint64_t*>(scratch);
+    uint32_t* nz_off = reinterpret_cast<uint32_t*>(gran + (int64_t)Bp * ntb);
+    int err = (int)hipMemsetAsync(gran, 0, (size_t)Bp * ntb * sizeof(uint64_t), st);   // the length words: not yet valid
+    if (err) return err;
+    convert_init_kernel<<<(Bp + 63) / 64, 64, 0, st>>>(nz_off, Bp, (uint32_t)(region_halfs / 8));
+    const Side s{static_cast<const uint16_t*>(x), (int64_t)t * kD, bmp, accum, nullptr, head_off, nullptr, nz_off, static_cast<uint16_t*>(regions),
+                 fresh_rows(t), region_halfs, 0, key ? 1 : 0};
+    compress_block_kernel<<<dim3(ntb, Bp, 1), 64, 0, st>>>(s, s, ntb, gran, overflow_flag, take_skip_publish());
+    head_offsets_kernel<<<1, kThreads, 0, st>>>(head_off, Bp);
+    return (int)hipGetLastError();
+}
+
+int mustafar_convert_pack(void* stream, const void* regions, int Bp, int t, int D, const int64_t* head_off, void* packed)
+{
+    if (D != kD || Bp < 1 || t < 64 || (t & 63) || !regions || !head_off) return MUSTAFAR_EINVAL;
+    if (!packed) return 0;   // nothing to write: every tile of every head is empty
+    const int64_t region_halfs = (int64_t)t * kD;
+    convert_pack_kernel<<<dim3((unsigned)((region_halfs / 8 + 1023) / 1024), Bp), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const uint16_t*>(regions), region_halfs, head_off, static_cast<uint16_t*>(packed));
+    return (int)hipGetLastError();
+}
+
 int mustafar_cache_append_bitmap_key(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
                                      int old_tokens, int64_t* head_total)
 {
@@ -909,7 +1023,7 @@ int mustafar_cache_append_kv(void* stream, const void* k_x, const void* v_x, int
         const int ntb = t / 64;
         const int err = (int)hipMemsetAsync(scratch, 0, 2 * (size_t)Bp * ntb * sizeof(uint64_t), st);   // the length words: not yet valid
         if (err) return err;
-        compress_block_kernel<<<dim3(ntb, Bp, 2), 64, 0, st>>>(s[0], s[1], ntb, static_cast<uint64_t*>(scratch), overflow_flag);
+        compress_block_kernel<<<dim3(ntb, Bp, 2), 64, 0, st>>>(s[0], s[1], ntb, static_cast<uint64_t*>(scratch), overflow_flag, take_skip_publish());
         return (int)hipGetLastError();
     }
     const int err = launch_meta(st, s, 2, Bp, t, static_cast<int32_t*>(scratch), overflow_flag, false);
@@ -937,6 +1051,7 @@ int mustafar_trigger_compress_batch(void* stream, int n, const mustafar_trigger_
             return MUSTAFAR_EINVAL;
     }
     const bool one_pass = one_pass_compress();
+    const int skip0 = take_skip_publish();   // (tests: the first layer's launch)
     if (one_pass) {
         const int err = (int)hipMemsetAsync(scratch, 0, (size_t)(per_item * n), st);   // the length words of every layer: not yet valid
         if (err) return err;
@@ -953,7 +1068,7 @@ int mustafar_trigger_compress_batch(void* stream, int n, const mustafar_trigger_
              nullptr, it.v_head_total, nullptr, it.v_dst.nz_offset, static_cast<uint16_t*>(it.v_dst.nz), vr, v_region_halfs, kth_v, 0}};
         unsigned char* sc = static_cast<unsigned char*>(scratch) + per_item * i;
         if (one_pass) {
-            compress_block_kernel<<<dim3(ntb, Bp, 2), 64, 0, st>>>(s[0], s[1], ntb, reinterpret_cast<uint64_t*>(sc), it.overflow_flag);
+            compress_block_kernel<<<dim3(ntb, Bp, 2), 64, 0, st>>>(s[0], s[1], ntb, reinterpret_cast<uint64_t*>(sc), it.overflow_flag, i == 0 ? skip0 : -1);
         } else {
             int err = launch_meta(st, s, 2, Bp, t, reinterpret_cast<int32_t*>(sc), it.overflow_flag, false);
             if (!err) err = launch_pack(st, s, 2, Bp, t, it.overflow_flag);
@@ -996,6 +1111,36 @@ int mustafar_cache_rehouse(void* stream, const mustafar_cache_view* src, const m
         src->idx_head_stride ? src->idx_head_stride : tiles + 1, dst->bmp, dst->idx, static_cast<uint16_t*>(dst->nz), dst->nz_offset,
         dst->bmp_head_stride ? dst->bmp_head_stride : tiles, dst->idx_head_stride ? dst->idx_head_stride : tiles + 1,
         (uint32_t)dst->nz_head_stride, tiles, stream_halfs);
+    return (int)hipGetLastError();
+}
+
+int mustafar_compress_set_form(int form)
+{
+    if (form < 0 || form > 2) return MUSTAFAR_EINVAL;
+    g_compress_form = form;
+    return 0;
+}
+
+int mustafar_compress_test_skip_publish(int block)
+{
+    g_skip_publish_tb = block < 0 ? -1 : block;
+    return 0;
+}
+
+int mustafar_cache_consolidate_extents(void* stream, const mustafar_cache_view* dst, const mustafar_cache_view* extents, int n_extents, int Bp,
+                                       int base_tokens, int64_t max_extent_halfs)
+{
+    if (!dst || !extents || n_extents < 1 || Bp < 1 || base_tokens < 0 || (base_tokens & 63) || max_extent_halfs < 0 || !dst->bmp || !dst->idx ||
+        !dst->nz || dst->nz_head_stride <= 0 || 3 * (int64_t)n_extents > 65535)
+        return MUSTAFAR_EINVAL;
+    const int64_t tiles = ((int64_t)base_tokens + 256ll * n_extents) * kD / 64;
+    if ((dst->bmp_head_stride ? dst->bmp_head_stride : tiles) < tiles || (dst->idx_head_stride ? dst->idx_head_stride : tiles + 1) < tiles + 1)
+        return MUSTAFAR_EINVAL;
+    int64_t largest = max_extent_halfs * 2 > (int64_t)kExtTiles * 8 ? max_extent_halfs * 2 : (int64_t)kExtTiles * 8;   // bytes of an extent's largest array (per head)
+    const unsigned gx = (unsigned)((largest + 16383) / 16384);
+    cache_consolidate_kernel<<<dim3(gx, Bp, 3 * n_extents), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        extents, (int)((int64_t)base_tokens * kD / 64), dst->bmp, dst->idx, static_cast<uint16_t*>(dst->nz),
+        dst->bmp_head_stride ? dst->bmp_head_stride : tiles, dst->idx_head_stride ? dst->idx_head_stride : tiles + 1, (uint32_t)dst->nz_head_stride);
     return (int)hipGetLastError();
 }
 

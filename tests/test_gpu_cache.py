@@ -408,29 +408,28 @@ def test_trigger_append_that_outgrows_the_expected_room_is_repeated_at_the_measu
     _assert_same_as_oracle(va, torch.cat([_oracle_pruned(V0, s, 512), _oracle_pruned(vw, s, 256)], 1), "value")
 
 
-def test_a_compression_timeout_is_its_own_error_and_leaves_the_cache_as_it_was():
-    """Bit 1 of the device flag (a block gave up waiting for its predecessors' lengths) cannot be provoked on demand; what the host
-    does with it can: the flag is pre-set, as if a block of this very launch had set it."""
-    from mustafar_amd import compression
-    from mustafar_amd.cache import ArenaAppendTimeout, CompressedArena
+def test_a_compression_timeout_is_answered_by_one_repeat_in_the_two_pass_form():
+    """Bit 1 of the device flag (a block gave up waiting for its predecessors' lengths): the flag is pre-set here, as if a block of this very
+    launch had set it (tests/test_gpu_extents.py provokes the real thing through mustafar_compress_test_skip_publish).  Round 4 raised
+    ArenaAppendTimeout and left the cache as it was; round 5 repeats the append once in the two-pass form -- the raw rows are still in
+    place, the call is idempotent -- counts it, and the cache holds exactly what an undisturbed append gives."""
+    from mustafar_amd import cache, compression
+    from mustafar_amd.cache import CompressedArena
     B, H, s = 1, 2, 0.7
     kth = compression.kth_from_sparsity(s, 128)
     K0, V0 = _raw(B, H, 256, 141), _raw(B, H, 256, 142)
     ka, va = CompressedArena.from_raw_pair(K0, V0, 256, kth, kth)
-    ref = [x.clone() for x in ka.to_reference()[:2]]
     kw, vw = _raw(B, H, 288, 143), _raw(B, H, 288, 144)
     for a in (ka, va):                                    # room as the call itself would make it, so that the flag tensor stays the one pre-set
         a._make_room(256, int(a.used.max()) + a._expected_append(256, kth))
     va._overflow = ka._overflow
     ka._overflow.fill_(2)
-    with pytest.raises(ArenaAppendTimeout):
-        CompressedArena.append_window_pair(ka, va, kw, vw, 256, kth, kth)
-    assert ka.tokens == va.tokens == 256 and int(ka._overflow) == 0
-    got = ka.to_reference()
-    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-    CompressedArena.append_window_pair(ka, va, kw, vw, 256, kth, kth)      # and the next append goes through
-    assert ka.tokens == 512
+    before = cache.compress_fallbacks
+    CompressedArena.append_window_pair(ka, va, kw, vw, 256, kth, kth)
+    assert cache.compress_fallbacks == before + 1
+    assert ka.tokens == va.tokens == 512 and int(ka._overflow) == 0
     _assert_same_as_oracle(ka, torch.cat([_oracle_pruned(K0, s, 256), _oracle_pruned(kw, s, 256)], 1), "key")
+    _assert_same_as_oracle(va, torch.cat([_oracle_pruned(V0, s, 256), _oracle_pruned(vw, s, 256)], 1), "value")
 
 
 def test_the_one_pass_form_refuses_to_run_without_a_flag():

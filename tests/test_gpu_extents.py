@@ -144,6 +144,40 @@ def test_full_table_consolidates_and_other_launch_forms_append_in_place(monkeypa
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(torch.cat(list(a[2])), torch.cat(list(b[2])))
 
 
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 8)])
+def test_consolidate_on_the_device_equals_the_host_round_trip(hq, hkv, monkeypatch):
+    """consolidate() (round 5): base + extents re-housed into one base by two launches -- the extents found through the device table the
+    decode launch reads, their offsets shifted by lengths read on the device -- equals the round-4 path through the reference layout on the
+    host (MUSTAFAR_CONSOLIDATE=host) and the cache's own reference layout, bit for bit; and decodes alike."""
+    torch.manual_seed(15)
+    bsz, D = 2, 128
+    L0, steps = 512 + R + 255, 1 + 2 * 256 + 2
+    K0, V0 = (torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(2))
+    qs = [torch.randn(bsz, hq, 1, D, device=DEV).half() for _ in range(steps)]
+    ks = [torch.randn(bsz, hkv, 1, D, device=DEV).half() for _ in range(steps)]
+    vs = [torch.randn(bsz, hkv, 1, D, device=DEV).half() for _ in range(steps)]
+    attn = _attn(hq, hkv)
+    _, past = _run(attn, K0, V0, qs, ks, vs)
+    assert len(past[0].extents) == 3 and past[0].tokens == 512 and past[4] == 512 + 768
+    for side in (0, 2):
+        arena = past[side]
+        dev_c = arena.consolidate()
+        monkeypatch.setenv("MUSTAFAR_CONSOLIDATE", "host")
+        host_c = arena.consolidate()
+        monkeypatch.delenv("MUSTAFAR_CONSOLIDATE")
+        assert not dev_c.extents and dev_c.tokens == host_c.tokens == past[4] and torch.equal(dev_c.used, host_c.used)
+        a, b, c = dev_c.to_reference(), host_c.to_reference(), arena.to_reference()
+        for x, y in ((a, b), (a, c)):
+            assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[3], y[3])
+            assert torch.equal(torch.cat(list(x[2])).view(torch.int16), torch.cat(list(y[2])).view(torch.int16))
+    q, k, v = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+    merged = (past[0].consolidate(), past[1].clone(), past[2].consolidate(), past[3].clone(), past[4], past[5])
+    merged[0].ext_table, merged[2].ext_table
+    o_m, _ = attn.decode(q, k, v, merged)
+    o_e, _ = attn.decode(q, k, v, (past[0], past[1].clone(), past[2], past[3].clone(), past[4], past[5]))
+    assert torch.equal(o_m, o_e) or (o_m.float() - o_e.float()).abs().max() <= 2 ** -10 * o_e.float().abs().max()   # (other workgroup boundaries: other slab sums)
+
+
 def test_engine_switch_to_a_form_without_extents_consolidates():
     """A cache that grew by extents handed to a launch form that reads one view (two launches asked for): decode_fused re-houses it
     once and goes on; outputs equal dense attention before and after."""
@@ -353,6 +387,52 @@ def test_batched_trigger_with_a_long_residual_window(residual):
             assert bat_p[l][4] == ref_p[l][4] and bat_p[l][1].len == ref_p[l][1].len == bat_p[l][3].len
             assert torch.equal(bat_p[l][1].view(), ref_p[l][1].view()) and torch.equal(bat_p[l][3].view(), ref_p[l][3].view())
     assert fired == 1 and bat_p[0][4] == 512 and bat_p[0][1].len == residual + 2
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_a_timed_out_one_pass_compression_is_repeated_in_the_two_pass_form(batched):
+    """Flag bit 1 of the one-pass compression launch -- a block gave up waiting for the lengths of the blocks in front of it; it relies on
+    in-order dispatch and has never been seen -- is FORCED here (mustafar_compress_test_skip_publish: block 1 of the next launch keeps its
+    length to itself, blocks 2 and 3 of every head time out): round 4 raised ArenaAppendTimeout, round 5 repeats the append once in the
+    two-pass form (the raw rows are still in place, the call is idempotent) and counts it.  Outputs, caches and windows equal the
+    undisturbed run bit for bit, layer by layer (decode) and through the batched trigger of all layers (run_triggers)."""
+    from mustafar_amd import _lib, cache
+    torch.manual_seed(16)
+    layers, bsz, hq, hkv, D = 2, 1, 8, 2, 128
+    L0 = 256 + R + 255                                   # the first decode step reaches the trigger
+    K0 = [torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(layers)]
+    V0 = [torch.randn(bsz, hkv, L0, D, device=DEV).half() for _ in range(layers)]
+    attn = _attn(hq, hkv)
+    ref_p = [attn.to_fused(attn.build_cache(K0[l].clone(), V0[l].clone())) for l in range(layers)]
+    tst_p = [attn.to_fused(attn.build_cache(K0[l].clone(), V0[l].clone())) for l in range(layers)]
+    qkv = [tuple(torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv)) for _ in range(layers)]
+    for l in range(layers):
+        _, ref_p[l] = attn.decode(*qkv[l], ref_p[l])
+    before = cache.compress_fallbacks
+    lib = _lib.load()
+    if batched:
+        for l in range(layers):
+            _, tst_p[l] = attn.decode_fused(*qkv[l], tst_p[l], defer_trigger=True)
+        pool = attn.prepare_triggers(tst_p)
+        assert lib.mustafar_compress_test_skip_publish(1) == 0
+        tst_p = attn.run_triggers(tst_p, pool)
+    else:
+        for l in range(layers):
+            if l == 0:
+                assert lib.mustafar_compress_test_skip_publish(1) == 0
+            _, tst_p[l] = attn.decode(*qkv[l], tst_p[l])
+    assert cache.compress_fallbacks == before + 1, "the forced time-out was not taken (or taken more than once)"
+    for l in range(layers):
+        assert tst_p[l][4] == ref_p[l][4] == 512 and len(tst_p[l][0].extents) == 1 and tst_p[l][1].len == ref_p[l][1].len == R
+        for side in (0, 2):
+            a, b = tst_p[l][side].to_reference(), ref_p[l][side].to_reference()
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(torch.cat(list(a[2])).view(torch.int16), torch.cat(list(b[2])).view(torch.int16))
+        assert torch.equal(tst_p[l][1].view(), ref_p[l][1].view())
+    q2 = [tuple(torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv)) for _ in range(layers)]
+    for l in range(layers):
+        o_ref, _ = attn.decode(*q2[l], ref_p[l])
+        o_tst, _ = attn.decode(*q2[l], tst_p[l])
+        assert torch.equal(o_ref, o_tst)
 
 
 def test_a_device_side_T_needs_the_step_counter():

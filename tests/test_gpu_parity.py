@@ -226,6 +226,27 @@ def test_compress_bit_exact(pkg, golden_dir, which):
             assert np.array_equal(nzs[b].cpu().numpy().view(np.uint16), c["nzs"][b].view(np.uint16))
 
 
+@pytest.mark.parametrize("which", ["key", "value"])
+def test_one_read_conversion_equals_the_two_pass_form(which):
+    """mustafar_convert_onepass / _pack (round 5: the rows read once, the sizes read on the host behind that work; MUSTAFAR_CONVERT=onepass)
+    against the default two-pass form, bit for bit: fixtures-sized and larger inputs, an all-zero block, rows without a single zero."""
+    from mustafar_amd import compression as comp
+    torch.manual_seed(3)
+    cases = [torch.from_numpy(make_cache(which, B, t, 128, s, seed)["pruned"]).to(DEV) for (B, t, s, seed) in [(5, 640, 0.7, 1), (3, 2048, 0.5, 2), (1, 64, 0.8, 3)]]
+    cases.append(torch.zeros((2, 128, 128), dtype=torch.float16, device=DEV))
+    dense = torch.randn((2, 192, 128), device=DEV).half()
+    dense[dense == 0] = 1
+    cases.append(dense)
+    for x in cases:
+        a_bmp, a_acc, a_nz = comp._convert(x, which)
+        b_bmp, b_acc, b_nz = comp._convert(x, which, onepass=True)
+        assert torch.equal(a_bmp, b_bmp) and torch.equal(a_acc, b_acc) and len(a_nz) == len(b_nz)
+        for p, q in zip(a_nz, b_nz):
+            assert torch.equal(p.view(torch.int16), q.view(torch.int16))
+        assert torch.cat(b_nz).data_ptr() == b_nz[0].data_ptr() if b_nz[0].numel() else True     # (pieces of one buffer: the free concatenation)
+    assert comp.convert_fallbacks == 0
+
+
 def test_empty_and_dense_blocks(pkg):
     """All-zero input (every tile empty, zero-length streams) and fully dense input (nnz = 64 everywhere)."""
     mp, comp = pkg
