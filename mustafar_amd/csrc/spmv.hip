@@ -2317,16 +2317,16 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
 // instead of two (round 5, decode_onepass_sb_kernel).  bmp_t / idx_t / cbase: block A's (block B's tiles lie 128 tiles behind; its e
 // segments -- VAL -- 512 bytes behind, its q rows are the same); bnd: A's three bounds in lanes 0..2, B's in lanes 8..10.
 //   mid1: called in front of chunk A1, mid3 in front of chunk B1 (the caller's requests for what comes next).
-template <int ENG, int HS, bool VAL, int G, class MID1, class MID3>
+template <int ENG, int HS, bool VAL, int G, class MID1, class MID3, class CBT = const void*, int EB = (VAL ? 4 * 64 * 2 : 0)>   // EB: coefficient offset of block B (bytes)
 __device__ __forceinline__ void lean_pair_phase(unsigned char* lds, uint32_t lds_addr, const uint64_t* __restrict__ bmp_t,
                                                 const uint32_t* __restrict__ idx_t, const unsigned char* __restrict__ nz_h,
-                                                const void* cbase, uint32_t bnd, int lane, float (&accA)[G], float (&accB)[G]
+                                                const CBT& cbase, uint32_t bnd, int lane, float (&accA)[G], float (&accB)[G]
 #ifdef MUSTAFAR_WAVE_TRACE
                                                 , PhaseTrace& phase_trace_
 #endif
                                                 , uint32_t ctab_lane, const MID1& mid1, const MID3& mid3)
 {
-    constexpr int kE = VAL ? 4 * 64 * 2 : 0;   // coefficient offset of block B (bytes): the next block's e segments; the same q rows
+    constexpr int kE = EB;   // coefficient offset of block B (bytes): the next block's e segments (one-pass launch); the same q rows (key phase)
     f32x4 mA = {0.f, 0.f, 0.f, 0.f}, mB = {0.f, 0.f, 0.f, 0.f};   // (ENG == 1 only)
     if constexpr (ENG == 1) {
         static_assert(ENG != 1 || G == 4, "the matrix-pipe engine multiplies four heads at a time");
@@ -2360,10 +2360,10 @@ __device__ __forceinline__ void lean_pair_phase(unsigned char* lds, uint32_t lds
             else if (k == 2) chunk32_mfma_at<128, 0>(adj, bmp_t, idx_t, ctab_lane + (VAL ? 4 * kValTabStride : 0), VAL ? mA : mB);
             else             chunk32_mfma_at<160, 64>(adj, bmp_t, idx_t, ctab_lane + (VAL ? 4 * kValTabStride : 0), VAL ? mA : mB);
         } else {
-            if (k == 0)      chunk32_at<ENG, 0, 0, HS, G, const void*, 32>(adj, bmp_t, idx_t, cbase, accA);
-            else if (k == 1) chunk32_at<ENG, 32, 64, HS, G, const void*, 128>(adj, bmp_t, idx_t, cbase, accA);
-            else if (k == 2) chunk32_at<ENG, 128, kE, HS, G, const void*, 160>(adj, bmp_t, idx_t, cbase, accB);
-            else             chunk32_at<ENG, 160, kE + 64, HS, G, const void*, -1>(adj, bmp_t, idx_t, cbase, accB);
+            if (k == 0)      chunk32_at<ENG, 0, 0, HS, G, CBT, 32>(adj, bmp_t, idx_t, cbase, accA);
+            else if (k == 1) chunk32_at<ENG, 32, 64, HS, G, CBT, 128>(adj, bmp_t, idx_t, cbase, accA);
+            else if (k == 2) chunk32_at<ENG, 128, kE, HS, G, CBT, 160>(adj, bmp_t, idx_t, cbase, accB);
+            else             chunk32_at<ENG, 160, kE + 64, HS, G, CBT, -1>(adj, bmp_t, idx_t, cbase, accB);
         }
         __builtin_amdgcn_wave_barrier();
         if (k < 3) {
@@ -3300,22 +3300,38 @@ __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
         for (int h = 0; h < G; h++) acc[h] = 0.f;
         if (live) {
             if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(1);
+            // round 5: a pair takes a contiguous half of the workgroup's blocks and walks it TWO blocks at a time as one pipeline of four
+            // chunks (lean_pair_phase: the next block's first chunk is in flight while this block's last one is worked on -- what the
+            // round-1 kernel's cross-block prefetch bought it over round 4's lean form); one body for both waves (biased pointers)
+            const int nblk = tb_end - tb0, nfirst = (nblk + 1) >> 1;
+            const int pb0 = tb0 + (pair ? nfirst : 0), pb_end = pair ? tb_end : tb0 + nfirst;
+            const uint64_t* vbo = vb + (odd ? 64 : 0);
+            const uint32_t* vio = vi + (odd ? 64 : 0);
+            const uint32_t off_bnd = (lane & 7) < 3 ? (lane & 7) * 128u : ((lane & 7) == 3 ? 64u : 192u);
+            const uint32_t off_bmp = (lane & 7) * 64u;
+            const bool lanesB = lane >= 8 && lane < 16;
 #pragma unroll 1
-            for (int t = tb0; t < tb_end; t += kWaves / 2) {
-                const int tb = t + pair;
-                if (tb < tb_end) {   // (wave-uniform; no barrier inside the loop: the pairs run freely)
-                    const uint64_t* vbt = vb + (int64_t)tb * kTilesPerTb;
-                    const uint32_t* vit = vi + (int64_t)tb * kTilesPerTb;
-                    const uint32_t bnd = bnd_load(vit, lane);
-                    const uint32_t pf = odd ? prefetch_meta_all<64, 64>(vbt, vit, lane) : prefetch_meta_all<0, 64>(vbt, vit, lane);
-                    CoefPtrs<G> cb;
+            for (int tb = pb0; tb < pb_end; tb += 2) {   // (wave-uniform; no barrier inside the loop: the pairs run freely)
+                const uint64_t* vbt = vbo + (int64_t)tb * kTilesPerTb;
+                const uint32_t* vit = vio + (int64_t)tb * kTilesPerTb;
+                const bool two = tb + 1 < pb_end;
+                uint32_t bnd = ld_at(vit, off_bnd);
+                if (two && lanesB) bnd = ld_at(vit + kTilesPerTb, off_bnd);
+                const uint32_t pfA = ld_at(vbt, off_bmp);
+                CoefPtrs<G> cb;
 #pragma unroll
-                    for (int h = 0; h < G; h++) cb.p[h] = p + ((int64_t)(bh0 + h) * N + n) * ldb + (int64_t)tb * 64;
-                    if (odd) lean_block_phase<0, 0, true, 2, 2, G, CoefPtrs<G>>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG);
-                    else     lean_block_phase<0, 0, true, 0, 2, G, CoefPtrs<G>>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG);
-                    prefetch_done(pf);
+                for (int h = 0; h < G; h++) cb.p[h] = p + ((int64_t)(bh0 + h) * N + n) * ldb + (int64_t)tb * 64;
+                if (two) {
+                    uint32_t pfB = 0;
+                    auto reqB = [&]() { pfB = ld_at(vbt + kTilesPerTb, off_bmp); };
+                    lean_pair_phase<0, 0, true, G, decltype(reqB), NoMid, CoefPtrs<G>, 64 * 2>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG, 0u, reqB,
+                                                                                                   NoMid());
+                    prefetch_done(pfB);
+                } else {
+                    lean_block_phase<0, 0, true, 0, 2, G, CoefPtrs<G>>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG);
                 }
-                if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(0);   // (the first block is done)
+                prefetch_done(pfA);
+                if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(0);   // (the first blocks are done)
             }
         }
         __syncthreads();   // every wave is done with its stage window (and with the previous row's sums)
@@ -3553,15 +3569,22 @@ inline int value_split()
 // c5 85.6 vs 76.8; N = 8 (the hook's padded rows): c3 55.7 vs 41.2 -- the round-1 kernel keeps its next block's bounds, metadata lines
 // and first chunk in flight while it works on the current one, which a value-only launch (no softmax step between the blocks) can do
 // and the lean block phase does not; lean addressing alone does not make up for it (profiles/r04_probes.txt).
+// Round 5: the lean form walks a pair's blocks two at a time as one pipeline of four chunks (lean_pair_phase) and is the default for N = 1
+// (the operands a caller of the C ABI / the hook's api="native" passes) up to ~24 k workgroup-blocks per launch: c2 22.5 -> 17.4 us, c3 30.8 ->
+// 28.0, c4 47.4 -> 45.1; c5 (32 k) 78.6 -> 80.6 and the hook's 8 padded rows (c3 41.6 -> 48.4) stay with round 1's kernel.  Its GQA-4
+// instantiation still spills (four coefficient pointers: 83 scalar + 12 vector spills) -- the next thing to fix there.
+// MUSTAFAR_VALUE_LEAN = 0 | 1 / mustafar_tune(7, .) force one form; unset (2): by size.
 int g_value_lean = -1;
-inline bool value_lean()
+inline int value_lean_mode()
 {
     if (g_value_lean < 0) {
         const char* e = getenv("MUSTAFAR_VALUE_LEAN");
-        g_value_lean = e ? atoi(e) != 0 : 0;
+        g_value_lean = e ? (atoi(e) != 0 ? 1 : 0) : 2;
     }
-    return g_value_lean != 0 && fma_engine() != 1;
+    return fma_engine() == 1 ? 0 : g_value_lean;
 }
+inline bool value_lean() { return value_lean_mode() == 1; }   // (forced on: the workgroup shape follows it, value_tb_stride)
+inline bool value_lean_for(int N, int64_t wg_blocks) { const int m = value_lean_mode(); return m == 1 || (m == 2 && N == 1 && wg_blocks < 24000); }
 inline int value_tb_stride() { return value_lean() ? kWaves / 2 : value_split() == 2 ? kValueWaves / 2 : kWaves; }   // token blocks in flight per workgroup
 
 // One place that picks the value kernel instantiation.
@@ -3577,7 +3600,7 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
         grid.y += wa.rows;
         if (window_rows_last(1)) wa.rows = -wa.rows;
     }
-    if (value_lean() && (N == 1 || N == 8)) {
+    if ((N == 1 || N == 8) && value_lean_for(N, (int64_t)(grid.y - (wa.rows < 0 ? -wa.rows : wa.rows)) * (T / 64))) {
 #define MUSTAFAR_LVL(GG)                                                                                                         \
     do {                                                                                                                         \
         if (N == 1) hipExtLaunchKernelGGL((value_lean_kernel<GG, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,  \
@@ -4129,7 +4152,7 @@ int mustafar_tune(int knob, int value)
         case 3: g_lean_win_last = value ? 1 : 0; return 0;
         case 4: g_pair_slabs = value ? 1 : 0; return 0;
         case 6: g_key_lean = value ? 1 : 0; return 0;
-        case 7: g_value_lean = value ? 1 : 0; return 0;
+        case 7: g_value_lean = value > 1 ? 2 : value ? 1 : 0; return 0;   // (2: by size, the default)
         case 8: g_sb = value ? 1 : 0; return 0;
         case 9: g_late_prio = value ? 1 : 0; return 0;
         default: return MUSTAFAR_EINVAL;

@@ -27,17 +27,35 @@ def segs():
     return st.get("segment.all.allocated", 0), st.get("num_alloc_retries", 0)
 
 
+# what a slow call coincides with (round 5: the 33-38 ms stall of "layer 14 of the second repetition", rounds 3 and 4): Python's cyclic garbage
+# collector (a full collection walks every tracked object of the process) and the allocator's driver segments are watched per call
+import gc
+gc_log = []
+_gc_t = [0.0]
+
+
+def _gc_cb(phase, info):
+    if phase == "start":
+        _gc_t[0] = time.perf_counter()
+    else:
+        gc_log.append((info["generation"], (time.perf_counter() - _gc_t[0]) * 1e3, info.get("collected", 0)))
+
+
+gc.callbacks.append(_gc_cb)
 for rep in range(3):
     s0 = segs()
     t0 = time.perf_counter()
-    slow = (0.0, -1)
+    slow = (0.0, -1, "")
     for l in range(layers):
+        n_gc, sg = len(gc_log), segs()[0]
         tl = time.perf_counter()
         CompressedArena.append_extent_pair(arenas[l][0], arenas[l][1], wk[l], wk[l], kth, kth)
-        slow = max(slow, (time.perf_counter() - tl, l))
+        dt_l = time.perf_counter() - tl
+        what = "; ".join("gc generation %d: %.2f ms (%d collected)" % g for g in gc_log[n_gc:]) or "no gc"
+        slow = max(slow, (dt_l, l, what + "; driver segments +%d" % (segs()[0] - sg)))
     torch.cuda.synchronize()
     s1 = segs()
-    print("            slowest layer of the repetition: layer %d, %.2f ms" % (slow[1], slow[0] * 1e3))
+    print("            slowest layer of the repetition: layer %d, %.2f ms  [%s]" % (slow[1], slow[0] * 1e3, slow[2]))
     print("per layer : append_extent_pair x32: %.2f ms   (driver segments allocated during it: %d, allocator retries: %d)"
           % ((time.perf_counter() - t0) * 1e3, s1[0] - s0[0], s1[1] - s0[1]))
 # what the FIRST batched trigger of a process pays beyond the later ones, taken apart: a one-layer rehearsal first
