@@ -2102,6 +2102,71 @@ __device__ __forceinline__ void fma8_d2(const u32x4 (&c)[4], Gathered2& g, float
                    MUSTAFAR_COPS(2), MUSTAFAR_COPS(3));
 }
 
+// Round 5, dot2 engine: the pair register built WITHOUT zeroing and WITHOUT switching EXEC per tile.  The gathers run unmasked (a lane
+// without an element reads a neighbouring half of the same stream: a valid LDS address, a value nobody uses), then per pair
+//   v_cndmask_b32      t_even, 0, t_even, mask_even                                   -> bits 15:0 = the even tile's element or 0, bits 31:16 = 0
+//   v_cndmask_b32_sdwa t_even, zero, t_odd, vcc (= mask_odd)  dst_sel:WORD_1 PRESERVE  -> bits 31:16 = the odd tile's element or 0
+// : two vector instructions per pair instead of three (two v_mov_b32 + v_or_b32), 6.0 per tile in the loop instead of 6.5, and one scalar
+// move per pair (vcc) instead of two (exec).  `zero`: a register holding 0 (SDWA takes no inline constant on gfx9).  A partial (dst_sel)
+// write needs one wait state before a vector instruction reads the register (gfx940+ forwarding hazard): the next pair's two selects
+// stand between a pair's SDWA write and its v_dot2 -- and an s_nop behind the last pair's.
+// MEASURED SLOWER (same box, kernel us, v_mov + v_or form / this form): c3 39.3-40.2 / 39.9-41.1, c4 66.5 / 68.6, c5 126.7 / 130.3 -- the v_mov_b32 and
+// v_or_b32 it saves are the two FULL-rate instructions of the loop (tools/ubench/issue_rates.hip: twice the rate of anything with a
+// scalar operand or a VOP3 / SDWA encoding), the two selects are not, and the masks now live to the FMA phase (68 scalar spills
+// instead of 44).  Off (MUSTAFAR_D2_SDWA = 0); kept as an experiment knob.
+#ifndef MUSTAFAR_D2_SDWA
+#define MUSTAFAR_D2_SDWA 0
+#endif
+#define MUSTAFAR_D2U_RANK(j, k)                                              \
+    "s_lshl2_add_u32 %[u" #k "], %[o" #j "], %[adj]\n\t"                     \
+    "v_mbcnt_lo_u32_b32 %[x" #k "], %[l" #j "], 0\n\t"                        \
+    "v_mbcnt_hi_u32_b32 %[x" #k "], %[h" #j "], %[x" #k "]\n\t"               \
+    "v_lshl_add_u32 %[x" #k "], %[x" #k "], 1, %[u" #k "]\n\t"
+#define MUSTAFAR_D2U_LOAD(j, k) "ds_read_u16 %[t" #j "], %[x" #k "]\n\t"
+struct Gathered2u {
+    uint32_t t[8];   // gathered halfs in bits 15:0 (garbage where the tile has no element in the lane: selected away by fma8_d2s)
+    uint64_t m[8];   // bit i <=> element i of the tile non-zero
+};
+__device__ __forceinline__ void gather8_d2u(const MetaB& m, uint32_t adj, Gathered2u& g)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) g.m[j] = __builtin_bitreverse64(m.bm[2 * j] | ((uint64_t)m.bm[2 * j + 1] << 32));
+    const uint64_t m0 = g.m[0], m1 = g.m[1], m2 = g.m[2], m3 = g.m[3], m4 = g.m[4], m5 = g.m[5], m6 = g.m[6], m7 = g.m[7];
+    uint32_t x0, x1, x2, x3, u0, u1, u2, u3;
+    asm volatile(MUSTAFAR_D2U_RANK(0, 0) MUSTAFAR_D2U_RANK(1, 1) MUSTAFAR_D2U_RANK(2, 2) MUSTAFAR_D2U_RANK(3, 3)
+                 MUSTAFAR_D2U_LOAD(0, 0) MUSTAFAR_D2U_LOAD(1, 1) MUSTAFAR_D2U_LOAD(2, 2) MUSTAFAR_D2U_LOAD(3, 3)
+                 MUSTAFAR_D2U_RANK(4, 0) MUSTAFAR_D2U_RANK(5, 1) MUSTAFAR_D2U_RANK(6, 2) MUSTAFAR_D2U_RANK(7, 3)
+                 MUSTAFAR_D2U_LOAD(4, 0) MUSTAFAR_D2U_LOAD(5, 1) MUSTAFAR_D2U_LOAD(6, 2) MUSTAFAR_D2U_LOAD(7, 3)
+                 : [t0] "=&v"(g.t[0]), [t1] "=&v"(g.t[1]), [t2] "=&v"(g.t[2]), [t3] "=&v"(g.t[3]), [t4] "=&v"(g.t[4]),
+                   [t5] "=&v"(g.t[5]), [t6] "=&v"(g.t[6]), [t7] "=&v"(g.t[7]), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2),
+                   [x3] "=&v"(x3), [u0] "=&s"(u0), [u1] "=&s"(u1), [u2] "=&s"(u2), [u3] "=&s"(u3)
+                 : MUSTAFAR_MOPS(0), MUSTAFAR_MOPS(1), MUSTAFAR_MOPS(2), MUSTAFAR_MOPS(3), MUSTAFAR_MOPS(4), MUSTAFAR_MOPS(5),
+                   MUSTAFAR_MOPS(6), MUSTAFAR_MOPS(7), [o0] "s"(m.ix[0]), [o1] "s"(m.ix[1]), [o2] "s"(m.ix[2]), [o3] "s"(m.ix[3]),
+                   [o4] "s"(m.ix[4]), [o5] "s"(m.ix[5]), [o6] "s"(m.ix[6]), [o7] "s"(m.ix[7]), [adj] "s"(adj)
+                 : "scc");
+}
+__device__ __forceinline__ void gather2u_wait(Gathered2u& g, u32x4 (&c)[4])   // drains the gathers and the coefficient loads
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.t[2]), "+v"(g.t[3]), "+v"(g.t[4]), "+v"(g.t[5]), "+v"(g.t[6]), "+v"(g.t[7]),
+                   "+s"(c[0]), "+s"(c[1]), "+s"(c[2]), "+s"(c[3]));
+}
+#define MUSTAFAR_D2S_PAIR(e, o)                                                                                         \
+    "v_cndmask_b32_e64 %[t" #e "], 0, %[t" #e "], %[m" #e "]\n\t"                                                        \
+    "s_mov_b64 vcc, %[m" #o "]\n\t"                                                                                     \
+    "v_cndmask_b32_sdwa %[t" #e "], %[z], %[t" #o "], vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0\n\t"
+__device__ __forceinline__ void fma8_d2s(const u32x4 (&c)[4], Gathered2u& g, uint32_t zero, float (&acc)[4])
+{
+    asm volatile(MUSTAFAR_D2S_PAIR(0, 1) MUSTAFAR_D2S_PAIR(2, 3) MUSTAFAR_DOT4(0, 0) MUSTAFAR_D2S_PAIR(4, 5) MUSTAFAR_DOT4(2, 1)
+                 MUSTAFAR_D2S_PAIR(6, 7) MUSTAFAR_DOT4(4, 2) "s_nop 0\n\t" MUSTAFAR_DOT4(6, 3)
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [t0] "+v"(g.t[0]), [t2] "+v"(g.t[2]),
+                   [t4] "+v"(g.t[4]), [t6] "+v"(g.t[6])
+                 : [t1] "v"(g.t[1]), [t3] "v"(g.t[3]), [t5] "v"(g.t[5]), [t7] "v"(g.t[7]), [z] "v"(zero),
+                   [m0] "s"(g.m[0]), [m1] "s"(g.m[1]), [m2] "s"(g.m[2]), [m3] "s"(g.m[3]), [m4] "s"(g.m[4]), [m5] "s"(g.m[5]),
+                   [m6] "s"(g.m[6]), [m7] "s"(g.m[7]), MUSTAFAR_COPS(0), MUSTAFAR_COPS(1), MUSTAFAR_COPS(2), MUSTAFAR_COPS(3)
+                 : "vcc");
+}
+
 // The matrix-pipe engine on the lean addressing: the dot2 form's gather (tile pairs packed in one register, exact zeros where a lane
 // has no element), then per FOUR tiles one v_mfma_f32_4x4x4_16B_f16 in place of eight v_dot2 -- the lane's A fragment is the four
 // coefficient halfs of head (lane % 4), read with one ds_read_b64 from a [4 heads][coefficients] table in LDS at ctab_lane =
@@ -2191,6 +2256,8 @@ __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restr
     constexpr bool kEarly = MUSTAFAR_META_EARLY > 1;
     MetaB cur, nxt;
     u32x4 c[G];
+    uint32_t zero = 0;   // (ENG == 2: the SDWA select's zero operand, held in a vector register)
+    if constexpr (ENG == 2 && MUSTAFAR_D2_SDWA) asm volatile("" : "+v"(zero));
     metab_issue_touch_at<TOFF, (NTOFF == -2 ? -1 : TOFF + 8)>(cur, bmp_t, idx_t);
     coef_issue_at<G, COFF, HS>(c, cbase);
     metab_wait(cur);
@@ -2198,11 +2265,19 @@ __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restr
     if constexpr (kEarly) metab_issue_touch_at<TOFF + 8 * (S + 1), MUSTAFAR_TT(S)>(nxt, bmp_t, idx_t); \
     if constexpr (ENG == 2) {                                   \
         if constexpr (G == 4) {                                 \
-            Gathered2 g;                                        \
-            gather8_d2(cur, adj, g);                            \
-            gather2_wait(g, c);                                 \
-            if constexpr (!kEarly) metab_issue_touch_at<TOFF + 8 * (S + 1), MUSTAFAR_TT(S)>(nxt, bmp_t, idx_t);  \
-            fma8_d2(c, g, acc);                                 \
+            if constexpr (MUSTAFAR_D2_SDWA) {                   \
+                Gathered2u g;                                   \
+                gather8_d2u(cur, adj, g);                       \
+                gather2u_wait(g, c);                            \
+                if constexpr (!kEarly) metab_issue_touch_at<TOFF + 8 * (S + 1), MUSTAFAR_TT(S)>(nxt, bmp_t, idx_t);  \
+                fma8_d2s(c, g, zero, acc);                      \
+            } else {                                            \
+                Gathered2 g;                                    \
+                gather8_d2(cur, adj, g);                        \
+                gather2_wait(g, c);                             \
+                if constexpr (!kEarly) metab_issue_touch_at<TOFF + 8 * (S + 1), MUSTAFAR_TT(S)>(nxt, bmp_t, idx_t);  \
+                fma8_d2(c, g, acc);                             \
+            }                                                   \
         }                                                       \
     } else {                                                    \
         Gathered g;                                             \
@@ -2218,10 +2293,17 @@ __device__ __forceinline__ void chunk32_at(uint32_t adj, const uint64_t* __restr
 #undef MUSTAFAR_STEP
     if constexpr (ENG == 2) {
         if constexpr (G == 4) {
-            Gathered2 g;
-            gather8_d2(cur, adj, g);
-            gather2_wait(g, c);
-            fma8_d2(c, g, acc);
+            if constexpr (MUSTAFAR_D2_SDWA) {
+                Gathered2u g;
+                gather8_d2u(cur, adj, g);
+                gather2u_wait(g, c);
+                fma8_d2s(c, g, zero, acc);
+            } else {
+                Gathered2 g;
+                gather8_d2(cur, adj, g);
+                gather2_wait(g, c);
+                fma8_d2(c, g, acc);
+            }
         }
     } else {
         Gathered g;
