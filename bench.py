@@ -773,7 +773,7 @@ def main():
     if world == 1 and not a.no_other_configs and a.api == "fused" and not a.no_graph:
         del w
         torch.cuda.empty_cache()
-        for name in ("c2", "c4", "c5"):
+        for name in ("c2", "c4", "c5", "b1"):   # (b1: the headline's geometry and length at batch 1 -- what single-user decode looks like; not a BASELINE config)
             if name != a.config:
                 sub[name] = run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib)
 

@@ -7,7 +7,7 @@
 # front of a `| grep` included (pipefail) -- stops the script, so nothing stale or truncated can be copied into profiles/ and a fault
 # under the profiler does not go unnoticed.
 set -e -o pipefail
-TAG=${1:-r04}; R=$(pwd); O=$R/gpurun_out/$TAG; rm -rf "$O"; mkdir -p "$O"
+TAG=${1:-r05}; R=$(pwd); O=$R/gpurun_out/$TAG; rm -rf "$O"; mkdir -p "$O"
 one_csv() { local n; n=$(ls $1 2>/dev/null | wc -l); [ "$n" = "1" ] || { echo "expected exactly one file for $1, found $n"; exit 1; }; ls $1; }
 nonempty() { [ -s "$1" ] || { echo "empty evidence file $1"; exit 1; }; }
 
@@ -43,9 +43,16 @@ python3 tools/bench_compress.py c3 c4 2> $O/compress.err | grep cfg > $O/compres
 python3 tools/bench_append.py 2> $O/append.err | grep cfg > $O/append.txt
 MUSTAFAR_FMA_ENGINE=valu python3 tools/microbench.py --cfg c3 c2 c3 c4 c5 --rows 1 8 --iters 30 2> $O/microbench.err | grep cfg > $O/microbench_valu.txt
 MUSTAFAR_FMA_ENGINE=mfma python3 tools/microbench.py --cfg c3 c3 c4 c5 --rows 1 --iters 30 2>> $O/microbench.err | grep cfg > $O/microbench_mfma.txt
-python3 tools/quick.py --cfg c2 c3 c4 c5 --set dot2 valu mfma valu:onepass=0 valu:lean=0 dot2:tbw=2 mfma:tbw=2 2> $O/quick.err | grep cfg > $O/structures.txt
-python3 tools/quick.py --cfg m8 g2 t8192 t8448 --set dot2 valu:onepass=0 2>> $O/quick.err | grep cfg >> $O/structures.txt
+python3 tools/quick.py --cfg c2 c3 c4 c5 --set dot2 valu mfma dot2:sb=0 valu:sb=0 mfma:sb=0 valu:onepass=0 dot2:tbw=1 2> $O/quick.err | grep cfg > $O/structures.txt
+python3 tools/quick.py --cfg m8 g2 b1 --set dot2 valu:onepass=0 2>> $O/quick.err | grep cfg >> $O/structures.txt
+# round 5: off the grid of whole rounds of workgroups (super-block form with / without the raised priority of a small last round, round 4's pair form)
+python3 tools/quick.py --cfg t8192 t8448 t8704 t8960 t9216 t10240 --set dot2 dot2:late=0 dot2:sb=0 2>> $O/quick.err | grep cfg > $O/offgrid.txt; nonempty $O/offgrid.txt
+tools/prof_cfgs.sh "c3 t8192 t8448 t8704" > $O/offgrid_kernel_stats.txt 2> $O/offgrid_kernel_stats.err; nonempty $O/offgrid_kernel_stats.txt
 python3 tools/bench_extent_append.py 2> $O/extent_append.err > $O/extent_append.txt; nonempty $O/extent_append.txt
+# round 5: the instruction classes of the timed kernel's ISA (static; tools/isa_breakdown.py) next to the counters
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 -S --cuda-device-only -o /tmp/spmv_isa.s mustafar_amd/csrc/spmv.hip 2> /dev/null
+{ echo "== decode_onepass_sb_kernel<2, false, 4, false, false> (dot2; the timed kernel): text between the trip markers holds the two-block pipelines AND the one-block alternatives: 384 tiles of text for the 256 a wave walks"; python3 tools/isa_breakdown.py /tmp/spmv_isa.s 'decode_onepass_sb_kernelILi2ELb0ELi4ELb0ELb0E' --tiles 384 --markers;
+  echo; echo "== decode_onepass_leanpair_kernel<2, false, 4> (round 4's kernel: one trip of its block loop, the even wave's path, 128 tiles)"; python3 tools/isa_breakdown.py /tmp/spmv_isa.s 'decode_onepass_leanpair_kernelILi2ELb0ELi4E'; } > $O/isa_breakdown.txt; nonempty $O/isa_breakdown.txt
 # only the summaries travel back (gpurun merges at most 64 MiB): the profiler's raw directories are dropped
 rm -rf $R/gpurun_out/pmc_${TAG}_* $R/gpurun_out/traffic_${TAG}_* $O/rocprof_bench
 echo "all done"; ls $O
