@@ -2397,9 +2397,9 @@ __device__ __forceinline__ void lean_block_phase(unsigned char* lds, uint32_t ld
 // TWO consecutive blocks (A and B = A + 1) of a wave's half -- its 64 tiles of each -- as ONE pipeline of four chunks (A0, A1, B0, B1): the
 // first chunk of B is in flight while the last chunk of A is worked on, so that a pair of phases starts with ONE exposed stream latency
 // instead of two (round 5, decode_onepass_sb_kernel).  bmp_t / idx_t / cbase: block A's (block B's tiles lie 128 tiles behind; its e
-// segments -- VAL -- 512 bytes behind, its q rows are the same); bnd: A's three bounds in lanes 0..2, B's in lanes 8..10.
+// segments -- VAL -- G x 128 bytes behind, its q rows are the same); bnd: A's three bounds in lanes 0..2, B's in lanes 8..10.
 //   mid1: called in front of chunk A1, mid3 in front of chunk B1 (the caller's requests for what comes next).
-template <int ENG, int HS, bool VAL, int G, class MID1, class MID3, class CBT = const void*, int EB = (VAL ? 4 * 64 * 2 : 0)>   // EB: coefficient offset of block B (bytes)
+template <int ENG, int HS, bool VAL, int G, class MID1, class MID3, class CBT = const void*, int EB = (VAL ? G * 64 * 2 : 0)>   // EB: coefficient offset of block B (bytes): its e rows lie G segments of 64 halfs behind block A's
 __device__ __forceinline__ void lean_pair_phase(unsigned char* lds, uint32_t lds_addr, const uint64_t* __restrict__ bmp_t,
                                                 const uint32_t* __restrict__ idx_t, const unsigned char* __restrict__ nz_h,
                                                 const CBT& cbase, uint32_t bnd, int lane, float (&accA)[G], float (&accB)[G]

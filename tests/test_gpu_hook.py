@@ -167,6 +167,34 @@ def test_alternative_kernel_forms_in_a_child_process(env):
     assert r.returncode == 0 and "alt-form ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("hq,hkv", [(8, 8), (8, 4), (8, 2)])
+@pytest.mark.parametrize("L0", [1312, 2100])
+def test_four_blocks_per_workgroup_for_every_group_count(hq, hkv, L0):
+    """The one-pass launch gives a workgroup four 64-token blocks -- each pair of waves two consecutive blocks as ONE pipeline, block B's e
+    segments G x 64 halfs behind block A's -- only when that leaves >= 1024 workgroups: MHA and GQA-2 reach that shape at 8k x batch 8, far
+    above the sizes of this suite (round 5 shipped a build whose G < 4 launches read block B's e at the G = 4 offset; bench-shape tests
+    are GQA-4 or small).  mustafar_tune(1, 2) forces the shape at a size dense attention checks in a second."""
+    from mustafar_amd import _lib
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    L = _lib.load()
+    torch.manual_seed(5)
+    bsz, D = 2, 128
+    attn = MustafarAttention(MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, api="fused"))
+    K = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    V = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    past = attn.to_fused(attn.build_cache(K.clone(), V.clone()))
+    assert L.mustafar_tune(1, 2) == 0
+    try:
+        for _ in range(3):
+            qn, kn, vn = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+            K, V = torch.cat([K, kn], 2), torch.cat([V, vn], 2)
+            C = past[4]
+            out, past = attn.decode(qn, kn, vn, past)
+            assert C >= 1024 and excess(out, _dense_reference(qn, K, V, C, 0.7, 0.7, hq // hkv), DENSE_ULPS) <= 1.0
+    finally:
+        L.mustafar_tune(1, 0)
+
+
 def test_fused_decode_with_rows_longer_than_32768():
     """Compressed length 33024 > 32768: the softmax runs in its streaming form (three passes over the row)."""
     from mustafar_amd.hook import MustafarAttention, MustafarConfig

@@ -33,11 +33,11 @@ def fma_engine(request):
     L = _lib.load()
     assert L.mustafar_set_fma_engine(1 if request.param == "mfma" else 0) == 0
     other = request.param.endswith("other-forms")
-    assert L.mustafar_tune(6, 0 if other else 1) == 0 and L.mustafar_tune(7, 1 if other else 0) == 0
+    assert L.mustafar_tune(6, 0 if other else 1) == 0 and L.mustafar_tune(7, 1 if other else 0) == 0   # (value: forced lean / forced round-1 kernel)
     yield request.param
     L.mustafar_set_fma_engine(2)   # the process defaults
     L.mustafar_tune(6, 1)
-    L.mustafar_tune(7, 0)
+    L.mustafar_tune(7, 2)   # (by size: the default since round 5)
 
 
 def _t(a, dtype=None):

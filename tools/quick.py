@@ -34,6 +34,7 @@ def main():
     lib = _lib.load()
     timer = bench.KernelTimer(mp)
     timer.install()
+    failed = []
     for name in a.cfg:
         w = bench.Workload(name, a.layers, dev, 0, 1, None, False, timer, lib)
         for st in a.set:
@@ -54,8 +55,12 @@ def main():
             print(json.dumps({"cfg": name, "set": st, "self_check_excess": round(ex, 3), "tok_s": round(w.batch * a.steps / dt, 1),
                               "ms_step": round(dt / a.steps * 1e3, 4), "kernel": rl["kernel"], "key_us": round(ku, 2), "value_us": round(vu, 2),
                               "frac": rl["frac"]}), flush=True)
+            if not ex <= 1.0:
+                failed.append((name, st, ex))
         del w
         torch.cuda.empty_cache()
+    if failed:   # (a timing of wrong results is no evidence: the collection scripts stop here)
+        raise SystemExit(f"quick.py: self-check FAILED (fused vs the reference entry points, x the fp16 bound): {failed}")
 
 
 if __name__ == "__main__":
