@@ -3195,15 +3195,16 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
     __syncthreads();   // every wave is done with its stage window
     if (has_heads && lane < HW) s_m[pair * G + h0 + lane] = lane ? m_run[HW - 1] : m_run[0];   // (each wave: the maxima of its heads)
     __syncthreads();
+    // lane h < G works out head h's weight (the four heads side by side: one exp for the wave, not one per head)
+    const int hl = lane & (G - 1);
+    const float mw = s_m[pair * G + hl];                         // the PAIR's maximum of head hl (kept by one of its two waves)
+    const float M = fmaxf(s_m[hl], s_m[G + hl]);
+    // a pair without blocks weighs nothing; the e scale leaves here (a power of two: exact)
+    const float scale_l = (mw == -INFINITY) ? 0.f : __expf(mw - M) * (ENG == 2 ? 0x1p-15f : 1.f);
+    if (has_heads && lane >= h0 && lane < h0 + HW) s_l[pair * G + lane] = (lane == h0 ? l_run[0] : l_run[HW - 1]) * scale_l;   // (the wave that finished the head)
 #pragma unroll
-    for (int h = 0; h < G; h++) {
-        const float mw = s_m[pair * G + h];                      // the PAIR's maximum of head h (kept by one of its two waves)
-        const float M = fmaxf(s_m[h], s_m[G + h]);
-        // a pair without blocks weighs nothing; the e scale leaves here (a power of two: exact)
-        const float scale = (mw == -INFINITY) ? 0.f : __expf(mw - M) * (ENG == 2 ? 0x1p-15f : 1.f);
-        if (lane == 0 && has_heads && h / HW == (G >= 2 ? odd : 0)) s_l[pair * G + h] = l_run[h % HW] * scale;   // (the wave that finished head h)
-        red[(wave * G + h) * 64 + lane] = acc[h] * scale;
-    }
+    for (int h = 0; h < G; h++)
+        red[(wave * G + h) * 64 + lane] = acc[h] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scale_l), h));
     __syncthreads();
     float* slab_o = a.ws_o + ((int64_t)blockIdx.x * a.BH + bh0) * kD;
     for (int o = threadIdx.x; o < 2 * G * 64; o += kThreads) {

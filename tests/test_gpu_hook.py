@@ -151,7 +151,8 @@ print("alt-form ok")
 
 
 @pytest.mark.parametrize("env", [{"MUSTAFAR_ONEPASS": "0"}, {"MUSTAFAR_ONEPASS": "1"}, {"MUSTAFAR_ONEPASS": "1", "MUSTAFAR_FMA_ENGINE": "mfma"},
-                                 {"MUSTAFAR_ONEPASS": "1", "MUSTAFAR_ONEPASS_WGS": "7"},
+                                 {"MUSTAFAR_ONEPASS": "1", "MUSTAFAR_ONEPASS_WGS": "7"}, {"MUSTAFAR_ONEPASS": "1", "MUSTAFAR_SB": "0"},
+                                 {"MUSTAFAR_ONEPASS": "1", "MUSTAFAR_SB": "0", "MUSTAFAR_FMA_ENGINE": "mfma"},
                                  {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_WINDOW": "rows"}, {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_WINDOW": "key"},
                                  {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_VALUE_SPLIT": "1"}, {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_KEY_LEAN": "0", "MUSTAFAR_KEY_SPLIT": "1"},
                                  {"MUSTAFAR_ONEPASS": "0", "MUSTAFAR_KEY_LEAN": "0", "MUSTAFAR_KEY_SPLIT": "2", "MUSTAFAR_FMA_ENGINE": "mfma"},
