@@ -3885,7 +3885,9 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                 // window workgroups BEHIND the SpMV rows (below) this is the better shape at c3 too -- round 3a, window rows first:
                 // 3968 workgroups of one pair each (tokens/s, four vs two blocks per workgroup, windows last: matrix pipe c3 6204 vs
                 // 6050, c4 1877 vs 1719, c5 4070 vs 3900; dot2 c3 5122 vs 4992).  MUSTAFAR_ONEPASS_WGS / MUSTAFAR_LEAN_TBW override
-                per_wg = (int64_t)((ntb + 3) / 4) * gy >= 1024 ? 4 : 2;
+                // (round 5, super-block form: from 768 workgroups -- three per CU -- on; Llama-3-8B 4k x batch 8 is 960 workgroups of four blocks:
+                // 23.5 vs 24.6 us; at 480 (c2) and 248 (8k x batch 1) two blocks per workgroup win, 13.3 vs 15.4 and 11.1 vs 14.6 us)
+                per_wg = (int64_t)((ntb + 3) / 4) * gy >= (g_sb ? 768 : 1024) ? 4 : 2;
                 (void)onepass_target_wgs(true);   // (reads MUSTAFAR_ONEPASS_WGS once)
                 if (g_onepass_wgs > 0) {
                     const int want = (g_onepass_wgs + gy - 1) / gy;
