@@ -2028,6 +2028,29 @@ __device__ __forceinline__ void coef_issue_at(u32x4 (&c)[G], const CoefPtrs<G>& 
     }
 }
 
+// The same rows through ONE base pointer and a scalar byte offset per further head (round 5): gfx950's scalar loads take a scalar
+// offset AND an immediate (s_load_dwordx4 sdst, sbase, soffset offset:imm), so rows a runtime distance apart cost three scalar
+// registers next to the base instead of three more pointers, and nothing but the base moves from block to block.
+template <int G>
+struct CoefStride {
+    const void* base;
+    uint32_t off[G > 1 ? G - 1 : 1];   // byte offsets of heads 1 .. G-1 from head 0
+};
+template <int G, int OFF, int HS>
+__device__ __forceinline__ void coef_issue_at(u32x4 (&c)[G], const CoefStride<G>& cb)
+{
+    if constexpr (G == 4) {
+        asm volatile("s_load_dwordx4 %0, %4, %8\n\ts_load_dwordx4 %1, %4, %5 offset:%8\n\t"
+                     "s_load_dwordx4 %2, %4, %6 offset:%8\n\ts_load_dwordx4 %3, %4, %7 offset:%8"
+                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3])
+                     : "s"(cb.base), "s"(cb.off[0]), "s"(cb.off[1]), "s"(cb.off[2]), "i"(OFF));
+    } else if constexpr (G == 2) {
+        asm volatile("s_load_dwordx4 %0, %2, %4\n\ts_load_dwordx4 %1, %2, %3 offset:%4" : "=&s"(c[0]), "=&s"(c[1]) : "s"(cb.base), "s"(cb.off[0]), "i"(OFF));
+    } else {
+        asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(c[0]) : "s"(cb.base), "i"(OFF));
+    }
+}
+
 struct Gathered2 {
     uint32_t t[8];   // gathered halfs, EXACT zero where the tile has no element in the lane: even tiles bits 15:0, odd tiles bits 31:16
 };
@@ -3228,7 +3251,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
 // compiled for 8 waves per SIMD.  Exact products only (v_fma_mix, or the matrix pipe for four heads): this is what an unchanged hook
 // calls.  N = rows per head of the dense operand: 1, or the hook's 8 (llama_mustafar_kernel.py:273: rows 1..7 are zero padding and
 // are written as exact zeros unless a row holds a non-zero, in which case it is computed like row 0).
-template <int G, int ENG, int N>
+template <int G, int ENG, int N, bool WIN = false>   // WIN: the launch carries window workgroups (fused two-launch decode); as value_lean_kernel
 __global__ MUSTAFAR_LP_BOUNDS void key_lean_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ q, h16* __restrict__ out, int T, int groups, int ldc, WinArgs wa,
@@ -3243,15 +3266,17 @@ __global__ MUSTAFAR_LP_BOUNDS void key_lean_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wrows = wa.rows < 0 ? -wa.rows : wa.rows;            // window rows lead (rows > 0) or trail (rows < 0) the grid
     const int wy = wa.rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
-    if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window scores
-        const int task = wy * gridDim.x + blockIdx.x;
-        if (task < (int)(gridDim.y - wrows) * wa.nchunks)
-            key_window_wg<G>(smem, q, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, out, T, ldc,
-                             groups, task);
-        MUSTAFAR_TRACE_END();
-        return;
+    if constexpr (WIN) {
+        if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window scores
+            const int task = wy * gridDim.x + blockIdx.x;
+            if (task < (int)(gridDim.y - wrows) * wa.nchunks)
+                key_window_wg<G>(smem, q, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, out, T, ldc,
+                                 groups, task);
+            MUSTAFAR_TRACE_END();
+            return;
+        }
     }
-    const int by = blockIdx.y - (wa.rows > 0 ? wa.rows : 0);
+    const int by = blockIdx.y - (WIN && wa.rows > 0 ? wa.rows : 0);
     const int hb_per_kv = groups / G;
     const int kvh = by / hb_per_kv;
     const int bh0 = kvh * groups + (by % hb_per_kv) * G;
@@ -3328,7 +3353,18 @@ __global__ MUSTAFAR_LP_BOUNDS void key_lean_kernel(
 // workgroup (two pairs) walks its token chunk two blocks at a time, every address inside a block is a base pointer + an immediate
 // (one pointer per head for the probabilities: their rows are N * ldb halfs apart, a runtime quantity), non-temporal stream loads,
 // 8 waves per SIMD, issue priority by progress.  v_fma_mix: exact products.  Slabs, flags and the combine pass as value_spmv_kernel.
-template <int G, int N>
+#ifndef MUSTAFAR_VL_STRIDE
+#define MUSTAFAR_VL_STRIDE 1   // the probabilities' rows through one base pointer + a scalar offset per head (0: a pointer per head, round 4 / 5a)
+#endif
+#if MUSTAFAR_VL_STRIDE
+#define MUSTAFAR_VL_COEF CoefStride
+#else
+#define MUSTAFAR_VL_COEF CoefPtrs
+#endif
+// WIN: the launch carries window workgroups (fused two-launch decode, N == 1).  An instantiation of its own: within this kernel's 64
+// vector registers the window path spills to scratch, and a kernel with a private segment -- even one its SpMV workgroups never touch --
+// is launched with scratch; the reference entry point (no window) must not pay for that.
+template <int G, int N, bool WIN = false>
 __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
@@ -3343,15 +3379,17 @@ __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wrows = wa.rows < 0 ? -wa.rows : wa.rows;            // window rows lead (rows > 0) or trail (rows < 0) the grid
     const int wy = wa.rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
-    if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window p.V -> slabs gridDim.x ..
-        const int task = wy * gridDim.x + blockIdx.x;
-        if (task < (int)(gridDim.y - wrows) * wa.nchunks)
-            value_window_wg<G, kWaves>(smem, p, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, ws,
-                                       (int64_t)BH * kD, gridDim.x, T, ldb, groups, task);
-        MUSTAFAR_TRACE_END();
-        return;
+    if constexpr (WIN) {
+        if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window p.V -> slabs gridDim.x ..
+            const int task = wy * gridDim.x + blockIdx.x;
+            if (task < (int)(gridDim.y - wrows) * wa.nchunks)
+                value_window_wg<G, kWaves>(smem, p, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, ws,
+                                           (int64_t)BH * kD, gridDim.x, T, ldb, groups, task);
+            MUSTAFAR_TRACE_END();
+            return;
+        }
     }
-    const int by = blockIdx.y - (wa.rows > 0 ? wa.rows : 0);
+    const int by = blockIdx.y - (WIN && wa.rows > 0 ? wa.rows : 0);
     const int hb_per_kv = groups / G;
     const int kvh = by / hb_per_kv;
     const int bh0 = kvh * groups + (by % hb_per_kv) * G;
@@ -3393,6 +3431,8 @@ __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
             const uint32_t off_bnd = (lane & 7) < 3 ? (lane & 7) * 128u : ((lane & 7) == 3 ? 64u : 192u);
             const uint32_t off_bmp = (lane & 7) * 64u;
             const bool lanesB = lane >= 8 && lane < 16;
+            const uint32_t head_bytes = (uint32_t)N * (uint32_t)ldb * 2u;   // (rows of consecutive heads; < 2^32: N * ldb < 2^31 halfs is checked by the launcher's T limit)
+            (void)head_bytes;
 #pragma unroll 1
             for (int tb = pb0; tb < pb_end; tb += 2) {   // (wave-uniform; no barrier inside the loop: the pairs run freely)
                 const uint64_t* vbt = vbo + (int64_t)tb * kTilesPerTb;
@@ -3401,17 +3441,23 @@ __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
                 uint32_t bnd = ld_at(vit, off_bnd);
                 if (two && lanesB) bnd = ld_at(vit + kTilesPerTb, off_bnd);
                 const uint32_t pfA = ld_at(vbt, off_bmp);
-                CoefPtrs<G> cb;
+                MUSTAFAR_VL_COEF<G> cb;
+#if MUSTAFAR_VL_STRIDE
+                cb.base = p + ((int64_t)bh0 * N + n) * ldb + (int64_t)tb * 64;
+#pragma unroll
+                for (int h = 1; h < G; h++) cb.off[h - 1] = (uint32_t)h * head_bytes;
+#else
 #pragma unroll
                 for (int h = 0; h < G; h++) cb.p[h] = p + ((int64_t)(bh0 + h) * N + n) * ldb + (int64_t)tb * 64;
+#endif
                 if (two) {
                     uint32_t pfB = 0;
                     auto reqB = [&]() { pfB = ld_at(vbt + kTilesPerTb, off_bmp); };
-                    lean_pair_phase<0, 0, true, G, decltype(reqB), NoMid, CoefPtrs<G>, 64 * 2>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG, 0u, reqB,
-                                                                                                   NoMid());
+                    lean_pair_phase<0, 0, true, G, decltype(reqB), NoMid, MUSTAFAR_VL_COEF<G>, 64 * 2>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG, 0u,
+                                                                                                           reqB, NoMid());
                     prefetch_done(pfB);
                 } else {
-                    lean_block_phase<0, 0, true, 0, 2, G, CoefPtrs<G>>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG);
+                    lean_block_phase<0, 0, true, 0, 2, G, MUSTAFAR_VL_COEF<G>>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG);
                 }
                 prefetch_done(pfA);
                 if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(0);   // (the first blocks are done)
@@ -3596,7 +3642,10 @@ void launch_key(hipStream_t st, const uint64_t* bmp, const unsigned char* nz, co
         const bool mf = G == 4 && fma_engine() == 1;
 #define MUSTAFAR_LKL(GG, EE)                                                                                                     \
     do {                                                                                                                         \
-        if (N == 1) hipExtLaunchKernelGGL((key_lean_kernel<GG, EE, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, q, out,   \
+        if (N == 1 && wa.rows != 0)                                                                                              \
+            hipExtLaunchKernelGGL((key_lean_kernel<GG, EE, 1, true>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, q, out,     \
+                                  T, groups, ldc, wa, bmp_stride, idx_stride, nz_stride);                                        \
+        else if (N == 1) hipExtLaunchKernelGGL((key_lean_kernel<GG, EE, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, q, out,   \
                                           T, groups, ldc, wa, bmp_stride, idx_stride, nz_stride);                                \
         else        hipExtLaunchKernelGGL((key_lean_kernel<GG, EE, 8>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, q, out,   \
                                           T, groups, ldc, wa, bmp_stride, idx_stride, nz_stride);                                \
@@ -3686,7 +3735,10 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
     if ((N == 1 || N == 8) && value_lean_for(N, (int64_t)(grid.y - (wa.rows < 0 ? -wa.rows : wa.rows)) * (T / 64))) {
 #define MUSTAFAR_LVL(GG)                                                                                                         \
     do {                                                                                                                         \
-        if (N == 1) hipExtLaunchKernelGGL((value_lean_kernel<GG, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,  \
+        if (N == 1 && wa.rows != 0)                                                                                                              \
+            hipExtLaunchKernelGGL((value_lean_kernel<GG, 1, true>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,    \
+                                  flags, T, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride);                    \
+        else if (N == 1) hipExtLaunchKernelGGL((value_lean_kernel<GG, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,  \
                                           flags, T, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride);            \
         else        hipExtLaunchKernelGGL((value_lean_kernel<GG, 8>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,  \
                                           flags, T, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride);            \
