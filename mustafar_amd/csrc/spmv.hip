@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
 #else
 #define MUSTAFAR_VALUE_BOUNDS __launch_bounds__(NW * 64, MF ? MUSTAFAR_VALUE_MF_WAVES : 1)
 #endif
-template <int G, bool MF, int NW, int SPLIT>
+template <int G, bool MF, int NW, int SPLIT, bool WIN = true>   // WIN = false: no window workgroups in the launch (the reference entry point): round 5, as key_lean_kernel
 __global__ MUSTAFAR_VALUE_BOUNDS void value_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ nz_off, const h16* __restrict__ p, h16* __restrict__ out, float* __restrict__ ws,
@@ -1056,15 +1056,17 @@ __global__ MUSTAFAR_VALUE_BOUNDS void value_spmv_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wrows = wa.rows < 0 ? -wa.rows : wa.rows;            // window rows lead (rows > 0) or trail (rows < 0) the grid
     const int wy = wa.rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
-    if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window p.V -> slabs gridDim.x ..
-        const int task = wy * gridDim.x + blockIdx.x;
-        if (task < (int)(gridDim.y - wrows) * wa.nchunks)
-            value_window_wg<G, NW>(smem, p, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, ws,
-                                   (int64_t)BH * kD, gridDim.x, T, ldb, groups, task);
-        MUSTAFAR_TRACE_END();
-        return;
+    if constexpr (WIN) {
+        if (wa.rows != 0 && wy >= 0 && wy < wrows) {   // fused decode only (N == 1): window p.V -> slabs gridDim.x ..
+            const int task = wy * gridDim.x + blockIdx.x;
+            if (task < (int)(gridDim.y - wrows) * wa.nchunks)
+                value_window_wg<G, NW>(smem, p, wa.win, wa.fresh, window_len(wa.w_extra, wa.w_len, wa.w_cap), wa.w_cap, wa.nchunks, ws,
+                                       (int64_t)BH * kD, gridDim.x, T, ldb, groups, task);
+            MUSTAFAR_TRACE_END();
+            return;
+        }
     }
-    const int by = blockIdx.y - (wa.rows > 0 ? wa.rows : 0);
+    const int by = blockIdx.y - (WIN && wa.rows > 0 ? wa.rows : 0);
     const int hb_per_kv = groups / G;
     const int kvh = by / hb_per_kv;
     const int bh0 = kvh * groups + (by % hb_per_kv) * G;
@@ -3751,11 +3753,17 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
     }
 #define MUSTAFAR_LV(GG, MFF)                                                                                                   \
     do {                                                                                                                       \
-        if (value_split() == 2)                                                                                                \
-            hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kValueWaves, 2>), grid, dim3(kValueWaves * 64), 0, st, ev0, ev1, 0, \
+        if (value_split() == 2 && wa.rows != 0)                                                                                \
+            hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kValueWaves, 2, true>), grid, dim3(kValueWaves * 64), 0, st, ev0, ev1, 0, \
+                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride); \
+        else if (value_split() == 2)                                                                                           \
+            hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kValueWaves, 2, false>), grid, dim3(kValueWaves * 64), 0, st, ev0, ev1, 0, \
+                                  bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride); \
+        else if (wa.rows != 0)                                                                                                 \
+            hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kWaves, 1, true>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,     \
                                   bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride); \
         else                                                                                                                   \
-            hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kWaves, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,           \
+            hipExtLaunchKernelGGL((value_spmv_kernel<GG, MFF, kWaves, 1, false>), grid, dim3(kThreads), 0, st, ev0, ev1, 0,    \
                                   bmp, nz, idx, nz_off, p, out, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride); \
     } while (0)
     switch (G) {
