@@ -22,6 +22,12 @@ the restoring -1 would switch lanes on that the program had switched off.
 register per kernel that the compiler does not know is pending; all of a kernel's sink loads must name the same register and no
 other instruction of the kernel may write it.
 
+(5) No private segment on the hot launches (round 5).  A kernel with a private segment -- a vector spill, or only the compiler's
+emergency slot with no scratch instruction in the text -- is launched with scratch; the key entry point lost 8-10 % to one that a
+branch it never takes (the fused decode's window workgroups) had brought in.  The kernels a default call reaches -- every
+decode_onepass_sb_kernel, the row kernel, and the entry-point instantiations WITHOUT a window path (template flag WIN = false) -- must
+report `.private_segment_fixed_size: 0` and no vector spill.
+
     python tools/check_smem_hazards.py [file.s]   # exit code 1 on a hazard; without a file spmv.hip is compiled
 """
 import os
@@ -257,22 +263,47 @@ def check(asm_text):
     return hazards, loads, waits, exec_stretches, sinks
 
 
+_SCRATCH_FREE = (r"decode_onepass_sb_kernel", r"onepass_finish_kernel", r"key_lean_kernelILi\dELi\dELi\dELb0E", r"value_lean_kernelILi\dELi\dELb0E",
+                 r"value_spmv_kernelILi\dELb[01]ELi\dELi\dELb0E", r"value_combine_kernel")
+
+
+def check_private_segments(asm_text):
+    """Check (5): [(kernel, bytes of private segment, vector spills)] of the hot kernels that have either."""
+    bad, seen = [], 0
+    for m in re.finditer(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", asm_text):
+        name, priv, vspill = m.group(1), int(m.group(2)), int(m.group(3))
+        if any(re.search(pat, name) for pat in _SCRATCH_FREE):
+            seen += 1
+            if priv or vspill:
+                bad.append((name, priv, vspill))
+    return bad, seen
+
+
+def _report_private(asm_text):
+    bad, seen = check_private_segments(asm_text)
+    print(f"hot kernels checked for a private segment: {seen}, with one: {len(bad)}")
+    for name, priv, vspill in bad:
+        print(f"  {name}: private segment {priv} bytes, vector spills {vspill}")
+    return 1 if bad or not seen else 0
+
+
 def main(asm_file=None):
     if asm_file:
         hazards, loads, waits, stretches, sinks = check(open(asm_file).read())
         print(f"scalar loads: {loads}, draining waits: {waits}, EXEC-masked stretches restored: {stretches}, prefetch sink loads: {sinks}, hazards: {len(hazards)}")
         for k, ln, code in hazards[:20]:
             print(f"  {k}: line {ln}: {code}")
-        return 1 if hazards else 0
+        return 1 if hazards or _report_private(open(asm_file).read()) else 0
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "spmv.s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16", "--cuda-device-only",
                                "-S", "-I" + os.path.join(ROOT, "include"), SRC, "-o", out], stderr=subprocess.DEVNULL)
-        hazards, loads, waits, stretches, sinks = check(open(out).read())
+        text = open(out).read()
+        hazards, loads, waits, stretches, sinks = check(text)
     print(f"scalar loads: {loads}, draining waits: {waits}, EXEC-masked stretches restored: {stretches}, prefetch sink loads: {sinks}, hazards: {len(hazards)}")
     for k, ln, code in hazards[:20]:
         print(f"  {k}: line {ln}: {code}")
-    return 1 if hazards else 0
+    return 1 if hazards or _report_private(text) else 0
 
 
 if __name__ == "__main__":
