@@ -172,7 +172,7 @@ def test_alternative_kernel_forms_in_a_child_process(env):
 @pytest.mark.parametrize("L0", [1312, 2100])
 def test_four_blocks_per_workgroup_for_every_group_count(hq, hkv, L0):
     """The one-pass launch gives a workgroup four 64-token blocks -- each pair of waves two consecutive blocks as ONE pipeline, block B's e
-    segments G x 64 halfs behind block A's -- only when that leaves >= 1024 workgroups: MHA and GQA-2 reach that shape at 8k x batch 8, far
+    segments G x 64 halfs behind block A's -- only when that leaves >= 768 workgroups (1024 when the bug was shipped): MHA and GQA-2 reach that shape at 8k x batch 8, far
     above the sizes of this suite (round 5 shipped a build whose G < 4 launches read block B's e at the G = 4 offset; bench-shape tests
     are GQA-4 or small).  mustafar_tune(1, 2) forces the shape at a size dense attention checks in a second."""
     from mustafar_amd import _lib
