@@ -1862,20 +1862,21 @@ constexpr int kMaxSlabs = 512;
 // Every wave works out the row's maximum, the slab weights and the denominator for ITSELF (lane = slab, DPP reductions, its own
 // LDS copy of the weights): no barrier before the weighted sum, one behind it to fold the two slab parities.  (Round 2 reduced
 // across the workgroup: five barriers in a kernel that is all latency; 5.4 -> 4.x us per layer at c3.)
+template <int KPER = kMaxSlabs / 64>   // slabs per lane of the weight pass: 64 * KPER >= S (round 5: c3's 36 slabs run the KPER = 1 text)
 __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml,
                                                              int S, h16* __restrict__ out, int BH)
 {
-    __shared__ float wgt_all[4][kMaxSlabs];
+    __shared__ float wgt_all[4][64 * KPER];
     __shared__ float part[kD];
     const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int c = tid & (kD - 1), par = tid >> 7;
     float* wgt = wgt_all[tid >> 6];
     const int64_t total = (int64_t)BH * kD;
     const float* src = ws_o + (int64_t)bh * kD + c;
-    // The first 64 slabs' outputs are requested BEFORE the weights are known: the loads fly while the maxima / sums are
+    // The first 2 * MUSTAFAR_FINISH_EARLY slabs' outputs are requested BEFORE the weights are known: the loads fly while the maxima / sums are
     // loaded and reduced (the kernel is two dependent memory round trips otherwise; 36-68 slabs at c3).
 #ifndef MUSTAFAR_FINISH_EARLY
-#define MUSTAFAR_FINISH_EARLY 32
+#define MUSTAFAR_FINISH_EARLY 20   // (round 5: 32 -> 20; c3's rows have 36 slabs: tokens/s + 1-2 % at c3, c4 / c5 unchanged -- same-box A/B, profiles/r05_probes.txt)
 #endif
     constexpr int kEarly = MUSTAFAR_FINISH_EARLY;   // per thread: slabs par, par + 2, ..., par + 2 * kEarly - 2 (128 slabs: a slab per pair at c3)
     float v[kEarly];
@@ -1884,7 +1885,7 @@ __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __rest
         const int k = par + 2 * i;
         v[i] = (k < S) ? src[(int64_t)k * total] : 0.f;
     }
-    constexpr int kPer = kMaxSlabs / 64;   // slabs lane, lane + 64, ... of the row, in every wave
+    constexpr int kPer = KPER;   // slabs lane, lane + 64, ... of the row, in every wave
     float m[kPer], l[kPer];
     float mx = -INFINITY;
 #pragma unroll
@@ -4024,8 +4025,15 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             }
 #undef MUSTAFAR_LL
             // (the row kernel's own start / stop timestamps go into the record's second event pair: mustafar_profile_end2)
-            hipExtLaunchKernelGGL(onepass_finish_kernel, dim3(Batch_Size), dim3(256), 0, st, prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr,
-                                  prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, 0, ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
+            if (NS + nchunks <= 64)
+                hipExtLaunchKernelGGL(onepass_finish_kernel<1>, dim3(Batch_Size), dim3(256), 0, st, prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr,
+                                      prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, 0, ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
+            else if (NS + nchunks <= 128)
+                hipExtLaunchKernelGGL(onepass_finish_kernel<2>, dim3(Batch_Size), dim3(256), 0, st, prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr,
+                                      prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, 0, ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
+            else
+                hipExtLaunchKernelGGL(onepass_finish_kernel<>, dim3(Batch_Size), dim3(256), 0, st, prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr,
+                                      prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, 0, ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
             if (prof) { g_prof.onepass++; g_prof.finish++; g_prof.n++; }
             t_last_choice = eng | (1 << 4) | ((lp ? (g_sb && per_wg <= 4 ? 3 : 2) : 1) << 8);
             return (int)hipGetLastError();
@@ -4080,7 +4088,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             }
 #undef MUSTAFAR_L1
             if (prof) { g_prof.onepass++; g_prof.n++; }
-            onepass_finish_kernel<<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, S1 + nchunks, static_cast<h16*>(out), Batch_Size);
+            onepass_finish_kernel<><<<Batch_Size, 256, 0, st>>>(ws_o, ws_ml, S1 + nchunks, static_cast<h16*>(out), Batch_Size);
             t_last_choice = (fma_engine() == 1 && G == 4 ? 1 : 0) | (1 << 4);
             return (int)hipGetLastError();
         }
