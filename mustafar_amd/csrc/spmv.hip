@@ -1912,13 +1912,29 @@ __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __rest
     const float denom = wave_sum(dsum);
     __builtin_amdgcn_wave_barrier();   // (the wave's own LDS writes, read back below: ordered within the wave)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if constexpr (kPer == 1) {
+        // one slab per lane: the weight of slab k is lane k's register, and k = par + 2 i is the same in every lane of the wave (par = wave / 2):
+        // a v_readlane per slab instead of an LDS round trip (the slabs beyond S were read as zero and weigh zero: lanes >= S hold w = 0)
+        const float w0 = (l[0] > 0.f) ? __expf(m[0] - M) : 0.f;
+        const int par_u = __builtin_amdgcn_readfirstlane(par);
 #pragma unroll
-    for (int i = 0; i < kEarly; i += 4) {   // (slabs beyond S were read as zero; their weights are never read)
-        const int k = par + 2 * i;
-        if (k < S)     s0 += wgt[k] * v[i];
-        if (k + 2 < S) s1 += wgt[k + 2] * v[i + 1];
-        if (k + 4 < S) s2 += wgt[k + 4] * v[i + 2];
-        if (k + 6 < S) s3 += wgt[k + 6] * v[i + 3];
+        for (int i = 0; i < kEarly; i += 4) {
+            static_assert(2 * kEarly + 1 <= 64, "the early slabs' weights are lanes of one register");
+            const int k = par_u + 2 * i;
+            s0 += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w0), k)) * v[i];
+            s1 += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w0), k + 2)) * v[i + 1];
+            s2 += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w0), k + 4)) * v[i + 2];
+            s3 += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w0), k + 6)) * v[i + 3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kEarly; i += 4) {   // (slabs beyond S were read as zero; their weights are never read)
+            const int k = par + 2 * i;
+            if (k < S)     s0 += wgt[k] * v[i];
+            if (k + 2 < S) s1 += wgt[k + 2] * v[i + 1];
+            if (k + 4 < S) s2 += wgt[k + 4] * v[i + 2];
+            if (k + 6 < S) s3 += wgt[k + 6] * v[i + 3];
+        }
     }
     int k = par + 2 * kEarly;
     for (; k + 6 < S; k += 8) {
