@@ -1950,6 +1950,45 @@ __global__ __launch_bounds__(256) void onepass_finish_kernel(const float* __rest
     if (!par) out[(int64_t)bh * kD + c] = (h16)((s + part[c]) / denom);
 }
 
+// The row kernel for rows of at most 64 slabs (round 5; every BASELINE shape up to 8k x batch 8): ONE thread per channel walks all the slabs of
+// the row -- no parity halves, no LDS, no barrier -- with the first kEarly1 slabs' outputs requested before the weights are known and each
+// weight taken from the lane that computed it (v_readlane; a slab per lane).  Two waves per row, each working the weights out for itself.
+#ifndef MUSTAFAR_FINISH1_EARLY
+#define MUSTAFAR_FINISH1_EARLY 40
+#endif
+__global__ __launch_bounds__(128) void onepass_finish1_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, int S,
+                                                              h16* __restrict__ out, int BH)
+{
+    constexpr int kEarly1 = MUSTAFAR_FINISH1_EARLY;
+    static_assert(kEarly1 <= 64 && kEarly1 % 4 == 0, "a slab per lane");
+    const int bh = blockIdx.x, c = threadIdx.x, lane = threadIdx.x & 63;
+    const int64_t total = (int64_t)BH * kD;
+    const float* src = ws_o + (int64_t)bh * kD + c;
+    float v[kEarly1];
+#pragma unroll
+    for (int i = 0; i < kEarly1; i++) v[i] = (i < S) ? src[(int64_t)i * total] : 0.f;
+    float m = -INFINITY, l = 0.f;
+    if (lane < S) {
+        const float2 ml = *reinterpret_cast<const float2*>(ws_ml + ((int64_t)lane * BH + bh) * 2);
+        m = ml.x;
+        l = ml.y;
+    }
+    const float M = wave_max(m);
+    const float w = (l > 0.f) ? __expf(m - M) : 0.f;   // (lanes >= S: zero)
+    const float denom = wave_sum(w * l);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    auto wk = [&](int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), k)); };
+#pragma unroll
+    for (int i = 0; i < kEarly1; i += 4) {
+        s0 += wk(i) * v[i];
+        s1 += wk(i + 1) * v[i + 1];
+        s2 += wk(i + 2) * v[i + 2];
+        s3 += wk(i + 3) * v[i + 3];
+    }
+    for (int k = kEarly1; k < S; k++) s0 += wk(k) * src[(int64_t)k * total];   // (S <= 64; wave-uniform k)
+    out[(int64_t)bh * kD + c] = (h16)(((s0 + s1) + (s2 + s3)) / denom);
+}
+
 // ------------------------------------------------------------------------------------------------ one-pass decode, lean form (G = 4)
 // Same algorithm and slabs as decode_onepass_kernel, rebuilt around what the round-2 counters showed: at c3 a workgroup of the
 // pair form runs its block loop ONCE, and 2.3 of its 11.3 vector instructions per tile were the start-up and merge code around
@@ -3587,6 +3626,7 @@ inline int onepass_target_wgs(bool pair)
 // GQA-4 one-pass launches on the vector engines: MUSTAFAR_ONEPASS_LEAN=2 (default) the lean kernel at the pair grain, 1 the lean
 // kernel with whole blocks per wave, 0 the round-2 pair form; MUSTAFAR_LEAN_TBW=n: blocks per wave (1) / block pairs per
 // workgroup (2) instead of the automatic choice (raised when the slabs would not fit).
+int g_finish1 = [] { const char* e = getenv("MUSTAFAR_FINISH1"); return e ? atoi(e) != 0 : 1; }();   // round 5: the one-thread-per-channel row kernel for rows of <= 64 slabs (mustafar_tune(10, v))
 int g_sb = [] { const char* e = getenv("MUSTAFAR_SB"); return e ? atoi(e) != 0 : 1; }();   // round 5: the super-block pair form (mustafar_tune(8, 0): round 4's pair kernel)
 int g_late_prio = 1;    // mustafar_tune(9, 0): no raised priority for a small last round of workgroups (experiments)
 int g_pair_slabs = 0;   // pair form, mustafar_tune(4, 1): a slab per pair instead of one per workgroup (kernel 1.1 us shorter at c3, row kernel 1.5 us longer)
@@ -4041,7 +4081,10 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             }
 #undef MUSTAFAR_LL
             // (the row kernel's own start / stop timestamps go into the record's second event pair: mustafar_profile_end2)
-            if (NS + nchunks <= 64)
+            if (NS + nchunks <= 64 && g_finish1)
+                hipExtLaunchKernelGGL(onepass_finish1_kernel, dim3(Batch_Size), dim3(128), 0, st, prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr,
+                                      prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, 0, ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
+            else if (NS + nchunks <= 64)
                 hipExtLaunchKernelGGL(onepass_finish_kernel<1>, dim3(Batch_Size), dim3(256), 0, st, prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr,
                                       prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, 0, ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
             else if (NS + nchunks <= 128)
@@ -4324,6 +4367,7 @@ int mustafar_tune(int knob, int value)
         case 7: g_value_lean = value > 1 ? 2 : value ? 1 : 0; return 0;   // (2: by size, the default)
         case 8: g_sb = value ? 1 : 0; return 0;
         case 9: g_late_prio = value ? 1 : 0; return 0;
+        case 10: g_finish1 = value ? 1 : 0; return 0;
         default: return MUSTAFAR_EINVAL;
     }
 }

@@ -49,6 +49,7 @@ def main():
             _lib.check(lib.mustafar_tune(4, int(kv.get("pslab", 0))), "pslab")
             _lib.check(lib.mustafar_tune(8, int(kv.get("sb", 1))), "sb")
             _lib.check(lib.mustafar_tune(9, int(kv.get("late", 1))), "late")
+            _lib.check(lib.mustafar_tune(10, int(kv.get("fin1", 1))), "fin1")
             ex = w.self_check()
             dt, (ku, vu, n) = w.timed_graph(a.steps, 3)
             rl = w.roofline(ku, vu, n, traffic_file=False)
