@@ -5,9 +5,10 @@ Same arguments, same return types as kernel/compression.py:249-339 and :341-432:
     (bitmaps int64 [B', t*D/64], accum_counts int32 [B', t*D/64 + 1], list of B' fp16 1-D tensors)
 computed by the HIP kernels in csrc/compress.hip behind the C ABI (include/mustafar_hip.h).  One small
 device->host read (B'+1 int64 offsets) remains because the packed sizes define the shapes of the returned
-tensors; the reference needs 1 + 2B' `.item()` syncs for the same reason (:308, :333-334).  Since round 5 the
-rows are read ONCE (the one-pass compression launch) and the read sits behind that work, in front of a copy
-launch that packs the streams into the exact-size buffer (rounds 1-4: two passes over the rows, the read between them).
+tensors; the reference needs 1 + 2B' `.item()` syncs for the same reason (:308, :333-334).  Two passes over the
+rows with the read between them (default); round 5 added the form that reads the rows ONCE (the one-pass compression
+launch into worst-case regions, the read behind it, a copy launch that packs the streams into the exact-size buffer):
+less GPU time, more wall time per call -- opt-in, MUSTAFAR_CONVERT=onepass.
 The per-head tensors are views of one packed buffer (the reference clones each slice, :335) and remember it: they are
 `StreamPiece`s, a tensor subclass whose only behaviour is that
     torch.cat(list of all the pieces of one buffer, in order)      (model :274, :314: once per layer and decode step)

@@ -3838,7 +3838,7 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
 
 extern "C" {
 
-int mustafar_abi_version(void) { return 104; }
+int mustafar_abi_version(void) { return 105; }   // 105 (round 5): mustafar_profile_end2, mustafar_convert_*, mustafar_cache_consolidate_extents, mustafar_compress_set_form
 
 int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
                    const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,

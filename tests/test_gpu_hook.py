@@ -196,6 +196,36 @@ def test_four_blocks_per_workgroup_for_every_group_count(hq, hkv, L0):
         L.mustafar_tune(1, 0)
 
 
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 8)])
+def test_both_row_kernels_of_short_rows(hq, hkv):
+    """Rows of <= 64 slabs are merged by onepass_finish1_kernel (one thread per channel, weights by v_readlane; round 5); mustafar_tune(10, 0)
+    keeps them on the 256-thread kernel (its one-slab-per-lane text, which no default launch reaches any more).  Both against dense attention,
+    and against each other within the rounding of one fp16 output."""
+    from mustafar_amd import _lib
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    L = _lib.load()
+    torch.manual_seed(9)
+    bsz, D, L0 = 2, 128, 1600
+    attn = MustafarAttention(MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, api="fused"))
+    K = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    V = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    past0 = attn.to_fused(attn.build_cache(K.clone(), V.clone()))
+    qn, kn, vn = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+    K, V = torch.cat([K, kn], 2), torch.cat([V, vn], 2)
+    want = _dense_reference(qn, K, V, past0[4], 0.7, 0.7, hq // hkv)
+    outs = []
+    try:
+        for form in (1, 0):
+            assert L.mustafar_tune(10, form) == 0
+            past = (past0[0], past0[1].clone(), past0[2], past0[3].clone(), past0[4], past0[5])
+            out, _ = attn.decode(qn, kn, vn, past)
+            assert excess(out, want, DENSE_ULPS) <= 1.0
+            outs.append(out.float())
+    finally:
+        L.mustafar_tune(10, 1)
+    assert (outs[0] - outs[1]).abs().max().item() <= 2 ** -10 * want.abs().max().item() + 1e-6
+
+
 def test_fused_decode_with_rows_longer_than_32768():
     """Compressed length 33024 > 32768: the softmax runs in its streaming form (three passes over the row)."""
     from mustafar_amd.hook import MustafarAttention, MustafarConfig
