@@ -199,6 +199,7 @@ class Workload:
         self.name, self.layers, self.dev, self.world, self.dist, self.rehearse = name, layers, dev, world, dist, rehearse
         self.timer, self.lib = timer, lib
         self.no_capture_ahead = os.environ.get("MUSTAFAR_BENCH_CAPTURE_AHEAD", "1") == "0"
+        self.inflight = int(os.environ.get("MUSTAFAR_BENCH_INFLIGHT", "0"))   # 0: the host queues every replay of the timed region at once
         self.label, self.Hq, self.Hkv, self.s, self.L, self.batch = CONFIGS[name]
         self.T = ((self.L - R) // 256) * 256
         self.BH = self.batch * self.Hq
@@ -436,7 +437,15 @@ class Workload:
                         box["pool"] = attn.prepare_triggers(fut)
                 box["g"].replay()
                 box["since"] += 1
+                if inflight:   # at most `inflight` replays queued behind the one the GPU works on (MUSTAFAR_BENCH_INFLIGHT; see the note at `inflight`)
+                    ev = ring[box["since"] % inflight]
+                    if ev[1]:
+                        ev[0].synchronize()
+                    ev[0].record(torch.cuda.current_stream(dev))
+                    ev[1] = True
 
+        inflight = self.inflight
+        ring = [[torch.cuda.Event(), False] for _ in range(inflight)]
         capture()
         box["reaches_trigger"] = warmup + steps >= until_trigger()
         for _ in range(warmup):
