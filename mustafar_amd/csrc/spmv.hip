@@ -3755,15 +3755,16 @@ inline int value_split()
     if (g_value_split) return g_value_split;
     return fma_engine() == 1 ? 1 : 2;   // the MFMA form needs > 80 VGPRs: 8-wave workgroups would drop to 4 waves per SIMD
 }
-// round 4: the lean pair form of the value entry point (value_lean_kernel, v_fma_mix engine) is OPT-IN -- MUSTAFAR_VALUE_LEAN=1 /
+// round 4: the lean pair form of the value entry point (value_lean_kernel, v_fma_mix engine) was opt-in -- MUSTAFAR_VALUE_LEAN=1 /
 // mustafar_tune(7, 1).  Measured against value_spmv_kernel (kernel + combine, us, N = 1): c3 28.0-29.9 vs 29.4-30.1, c4 48.8 vs 46.7,
 // c5 85.6 vs 76.8; N = 8 (the hook's padded rows): c3 55.7 vs 41.2 -- the round-1 kernel keeps its next block's bounds, metadata lines
 // and first chunk in flight while it works on the current one, which a value-only launch (no softmax step between the blocks) can do
 // and the lean block phase does not; lean addressing alone does not make up for it (profiles/r04_probes.txt).
 // Round 5: the lean form walks a pair's blocks two at a time as one pipeline of four chunks (lean_pair_phase) and is the default for N = 1
 // (the operands a caller of the C ABI / the hook's api="native" passes) up to ~24 k workgroup-blocks per launch: c2 22.5 -> 17.4 us, c3 30.8 ->
-// 28.0, c4 47.4 -> 45.1; c5 (32 k) 78.6 -> 80.6 and the hook's 8 padded rows (c3 41.6 -> 48.4) stay with round 1's kernel.  Its GQA-4
-// instantiation still spills (four coefficient pointers: 83 scalar + 12 vector spills) -- the next thing to fix there.
+// 28.0, c4 47.4 -> 45.1; c5 (32 k) 78.6 -> 80.6 and the hook's 8 padded rows (c3 41.6 -> 48.4) stay with round 1's kernel.  (Its GQA-4
+// instantiation spilled 83 scalar + 12 vector registers: the window path it carried and four coefficient pointers -- both gone since round 5b:
+// template flag WIN, CoefStride; 21 scalar spills, no private segment.  The call stays 26-27 us at c3: ~22 us of kernel + the combine launch.)
 // MUSTAFAR_VALUE_LEAN = 0 | 1 / mustafar_tune(7, .) force one form; unset (2): by size.
 int g_value_lean = -1;
 inline int value_lean_mode()
