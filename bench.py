@@ -77,8 +77,8 @@ API_NOTE = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
