@@ -246,21 +246,18 @@ __device__ __forceinline__ void metab_issue(MetaB& m, const uint64_t* __restrict
                  : "=&s"(m.bm), "=&s"(m.ix)
                  : "s"(bmp), "s"(idx), "i"(S * 64), "i"(S * 32));
 }
-#ifdef MUSTAFAR_PROBE_NOMETAWAIT   // timing-only build: the next step does not wait for its metadata; results wrong (LDS reads out of range return 0)
-#if MUSTAFAR_META_TOUCH
-#define MUSTAFAR_MOPS_T , "+s"(m.t0), "+s"(m.t1)
-#else
-#define MUSTAFAR_MOPS_T
+#ifdef MUSTAFAR_PROBE_NOMETAWAIT
+// (rounds 3-5 had a timing-only build here whose next step did not wait for its metadata.  It consumed scalar registers that
+// s_load_dwordx16 / x8 were still writing -- as STREAM OFFSETS of the gathers and, through the chunk bounds, of global loads -- and
+// took a GPU box down with a memory-access fault twice (profiles/r05_probes.txt item 3).  Removed in round 6: it cannot be built.)
+#error "MUSTAFAR_PROBE_NOMETAWAIT was removed: it uses registers a scalar load is still writing as addresses (GPU memory-access fault)"
 #endif
-__device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_nop 0" : "+s"(m.bm), "+s"(m.ix) MUSTAFAR_MOPS_T); }
-#else
 #if MUSTAFAR_META_TOUCH
 #define MUSTAFAR_MOPS_T , "+s"(m.t0), "+s"(m.t1)
 #else
 #define MUSTAFAR_MOPS_T
 #endif
 __device__ __forceinline__ void metab_wait(MetaB& m) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.bm), "+s"(m.ix) MUSTAFAR_MOPS_T); }
-#endif
 // Ordering point without an instruction: legal right after a wait that already drained the counter.
 __device__ __forceinline__ void metab_ready(MetaB& m) { asm volatile("" : "+s"(m.bm), "+s"(m.ix) MUSTAFAR_MOPS_T); }
 

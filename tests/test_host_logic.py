@@ -225,6 +225,43 @@ def test_no_read_of_an_in_flight_scalar_load_in_the_spmv_isa():
     assert mod.main() == 0
 
 
+def test_build_variant_refuses_an_isa_that_fails_the_hazard_checks():
+    """tools/build_variant.sh (round 6): a probe / experiment library is only emitted when its ISA passes checks (1)-(4) of
+    tools/check_smem_hazards.py.  One allowed variant (a row-kernel knob: the ISA stays clean, the library is written) and one refused
+    one (-DMUSTAFAR_META_EARLY=2: the compiler spills scalar registers that loads are still writing -- DESIGN 4.1 item 6 -- exit code 3,
+    no library), built side by side; the knob of round 5's faulting probe does not compile at all any more."""
+    import subprocess
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    script = os.path.join(ROOT, "tools", "build_variant.sh")
+    vdir = os.path.join(ROOT, "mustafar_amd", "lib", "variants")
+    names = {"ok": "citest_allowed", "bad": "citest_refused", "gone": "citest_nometawait"}
+    for n in names.values():
+        try:
+            os.remove(os.path.join(vdir, f"libmustafar_hip_{n}.so"))
+        except OSError:
+            pass
+    procs = {"ok": subprocess.Popen(["bash", script, names["ok"], "-DMUSTAFAR_FINISH_EARLY=16"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True),
+             "bad": subprocess.Popen(["bash", script, names["bad"], "-DMUSTAFAR_META_EARLY=2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True),
+             "gone": subprocess.Popen(["bash", script, names["gone"], "-DMUSTAFAR_PROBE_NOMETAWAIT"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)}
+    out = {k: p.communicate(timeout=900) for k, p in procs.items()}
+    try:
+        assert procs["ok"].returncode == 0, out["ok"][1][-2000:]
+        assert os.path.exists(os.path.join(vdir, f"libmustafar_hip_{names['ok']}.so"))
+        assert procs["bad"].returncode == 3, (procs["bad"].returncode, out["bad"][1][-2000:])
+        assert "REFUSED" in out["bad"][1] and "hazards:" in out["bad"][1]
+        assert not os.path.exists(os.path.join(vdir, f"libmustafar_hip_{names['bad']}.so"))
+        assert procs["gone"].returncode not in (0, 3) and "MUSTAFAR_PROBE_NOMETAWAIT was removed" in out["gone"][1]
+        assert not os.path.exists(os.path.join(vdir, f"libmustafar_hip_{names['gone']}.so"))
+    finally:
+        for n in names.values():
+            try:
+                os.remove(os.path.join(vdir, f"libmustafar_hip_{n}.so"))
+            except OSError:
+                pass
+
+
 def test_stream_pieces_make_the_hooks_torch_cat_free():
     """compression.StreamPiece (CPU tensors suffice): `torch.cat` of all the pieces of one buffer, in order, IS that buffer (model
     :274, :314); the trigger's per-head `torch.cat([old[b], new[b]])` (model :368, :390) fills one new buffer whose pieces
