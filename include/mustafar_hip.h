@@ -261,11 +261,13 @@ int mustafar_cache_rehouse(void* stream, const mustafar_cache_view* src, const m
  * on: 0 = the process default (one pass unless MUSTAFAR_COMPRESS=twopass is in the environment), 1 = one pass, 2 = the two-pass form (three
  * launches, no wait between workgroups).  Round 5: a caller whose one-pass launch reported flag bit 1 (a block gave up waiting for the
  * lengths in front of it) repeats the call ONCE in the two-pass form -- the raw rows are still in place, the call is idempotent -- instead
- * of failing (cache.py; counted in cache.compress_fallbacks).  Process-wide state: set it, call, set it back.
- * mustafar_compress_test_skip_publish (tests only): the block of this index of the NEXT one-pass launch does not publish its length, so
- * that every block behind it times out (bit 1); -1 = off.
+ * of failing (cache.py; counted in cache.compress_fallbacks).  State of the calling host THREAD (round 6; it was process-wide): read the
+ * current value (mustafar_compress_get_form), set it, call, set the old value back.
+ * mustafar_compress_test_skip_publish (tests only; MUSTAFAR_EINVAL unless the process runs with MUSTAFAR_TEST_HOOKS=1): the block of this
+ * index of the calling thread's NEXT one-pass launch does not publish its length, so that every block behind it times out (bit 1); -1 = off.
  */
 int mustafar_compress_set_form(int form);
+int mustafar_compress_get_form(void);
 int mustafar_compress_test_skip_publish(int block);
 /*
  * consolidate() on the device (round 5): the `n_extents` appended extents of a cache, read through its DEVICE table of views (the table

@@ -74,6 +74,7 @@ SIGNATURES = {
     "mustafar_compress_pack_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mustafar_cache_consolidate_extents": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64]),
     "mustafar_compress_set_form": (_i32, [_i32]),
+    "mustafar_compress_get_form": (_i32, []),
     "mustafar_compress_test_skip_publish": (_i32, [_i32]),
     "mustafar_convert_scratch_bytes": (_i64, [_i32, _i32]),
     "mustafar_convert_onepass": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

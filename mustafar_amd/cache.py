@@ -189,7 +189,9 @@ class CompressedArena:
     def _settle(self, wait: bool = True) -> None:
         """Take in the lengths and the flag of an asynchronous append (see the module docstring).  wait=False: only if the copy
         has landed already (the decode path calls this before every read of the arena: no host stall, and a failed append
-        is reported before the cache is used again rather than 256 steps later)."""
+        is reported before the cache is used again rather than 256 steps later).  Unlike the synchronous appends this path has NO
+        repeat in the two-pass form: by the time its flag is read the raw rows have slid out of the window, so a timeout (bit 1)
+        rolls the token count back and raises ArenaAppendTimeout."""
         if self._pending is None:
             return
         ev, t = self._pending
@@ -360,6 +362,7 @@ class CompressedArena:
         global compress_fallbacks
         for i in redo:                                # bit 0: on its own, at the size the launch reported (append_window_pair's repeat);
             (ka, va), (kr, vr) = pairs[i], rows[i]    # bit 1: on its own in the two-pass form, which has no wait between workgroups
+            prev_form = L.mustafar_compress_get_form()   # (this thread's; restored, not reset: a caller may have chosen a form itself)
             if i in timed_out:
                 compress_fallbacks += 1
                 _lib.check(L.mustafar_compress_set_form(2), "mustafar_compress_set_form")
@@ -367,7 +370,7 @@ class CompressedArena:
                 CompressedArena.append_extent_pair(ka, va, kr, vr, kth_k, kth_v)
             finally:
                 if i in timed_out:
-                    L.mustafar_compress_set_form(0)
+                    L.mustafar_compress_set_form(prev_form)
             with torch.cuda.device(dev):
                 _lib.check(L.mustafar_window_drop_front(torch.cuda.current_stream(dev).cuda_stream, kr.data_ptr(), vr.data_ptr(), head_stride,
                                                         H, window_len, 256), "mustafar_window_drop_front")
@@ -393,6 +396,8 @@ class CompressedArena:
             used += u
         total = self.total_tokens
         new = CompressedArena(self.heads, self.which, self.device, _cap_rows(total, self.slack), _cap_nz(int(used.max()), self.slack), self.slack)
+        if int(used.max()) > new.nz_cap:   # (the device copy trusts these host-side lengths for the size of the regions)
+            raise RuntimeError("CompressedArena.consolidate: a head's summed stream length exceeds the new region: this is a bug")
         L = _lib.load()
         with torch.cuda.device(self.device):
             st = torch.cuda.current_stream(self.device).cuda_stream
@@ -533,13 +538,14 @@ class CompressedArena:
             twopass = False
             attempt = 0
             while True:
+                prev_form = _lib.load().mustafar_compress_get_form()   # (this thread's; restored, not reset)
                 if twopass:
                     _lib.check(_lib.load().mustafar_compress_set_form(2), "mustafar_compress_set_form")
                 try:
                     CompressedArena._launch_pair(k_arena, v_arena, k_rows, v_rows, t, kth_k, kth_v)
                 finally:
                     if twopass:
-                        _lib.load().mustafar_compress_set_form(0)
+                        _lib.load().mustafar_compress_set_form(prev_form)
                 # flag and lengths: three small copies into pinned memory, ONE wait (for the launch and the copies)
                 host = k_arena._host_landing()
                 host[0][:1].copy_(k_arena._overflow, non_blocking=True)

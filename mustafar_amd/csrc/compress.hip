@@ -700,7 +700,8 @@ __global__ __launch_bounds__(kThreads) void cache_rehouse_kernel(const uint64_t*
                                                                  int64_t tiles, int64_t nz_halfs)
 {
     const int h = blockIdx.y, which = blockIdx.z;
-    const int64_t piece = (int64_t)blockIdx.x * 1024 + threadIdx.x;   // 16-byte units, 4 per thread and piece
+    static_assert(kThreads == 256, "a workgroup of this kernel moves pieces of 4 x kThreads = 1024 16-byte units (the host sizes grid.x for that)");
+    const int64_t piece = (int64_t)blockIdx.x * (4 * kThreads) + threadIdx.x;   // 16-byte units, 4 per thread and piece
     if (which == 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) d_off[h] = (uint32_t)h * d_nz_stride;
         const uint4* src = reinterpret_cast<const uint4*>(s_bmp + h * s_bmp_stride);
@@ -751,28 +752,36 @@ __global__ __launch_bounds__(kThreads) void cache_consolidate_kernel(const musta
         __syncthreads();
         before = s_before;
     }
-    const int64_t piece = (int64_t)blockIdx.x * 1024 + threadIdx.x;   // 16-byte units, 4 per thread and piece
+    static_assert(kThreads == 256, "a workgroup of this kernel moves pieces of 4 x kThreads = 1024 16-byte units (the host sizes grid.x for that)");
+    const int64_t piece = (int64_t)blockIdx.x * (4 * kThreads) + threadIdx.x;   // 16-byte units, 4 per thread and piece
     if (which == 0) {
         const uint4* src = reinterpret_cast<const uint4*>(v.bmp + (int64_t)h * v.bmp_head_stride);
         uint4* dst = reinterpret_cast<uint4*>(d_bmp + h * d_bmp_stride + tile0);
         const int64_t n = kExtTiles / 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int64_t p = piece + i * 256; if (p < n) dst[p] = src[p]; }
+        for (int i = 0; i < 4; i++) { const int64_t p = piece + i * kThreads; if (p < n) dst[p] = src[p]; }
     } else if (which == 1) {
+        // entry 0 of an extent IS entry kExtTiles of the one in front of it (or the base's last entry, which other workgroups read as
+        // `before`): it is written once, by its owner -- an extent writes entries 1 .. kExtTiles (round 6; before, neighbours wrote the
+        // shared entry twice)
         uint32_t* dst = d_idx + h * d_idx_stride + tile0;
-        for (int64_t p = (int64_t)blockIdx.x * 4096 + threadIdx.x; p < (int64_t)(blockIdx.x + 1) * 4096 && p <= kExtTiles; p += kThreads) dst[p] = e_idx[p] + before;
+        for (int64_t p = (int64_t)blockIdx.x * (16 * kThreads) + threadIdx.x; p < (int64_t)(blockIdx.x + 1) * (16 * kThreads) && p <= kExtTiles; p += kThreads)
+            if (p > 0) dst[p] = e_idx[p] + before;   // (an extent's own offsets start at 0)
     } else {
         const uint4* src = reinterpret_cast<const uint4*>(v.nz) + (int64_t)h * v.nz_head_stride;
         uint4* dst = reinterpret_cast<uint4*>(d_nz) + (int64_t)h * d_nz_stride + before / 4;   // (lengths are multiples of four half2: 16 bytes)
         const int64_t n = e_idx[kExtTiles] / 4;
+        const int64_t room = (int64_t)d_nz_stride - before / 4;   // (the host sizes the regions from the heads' summed lengths; never write past one)
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int64_t p = piece + i * 256; if (p < n) dst[p] = src[p]; }
+        for (int i = 0; i < 4; i++) { const int64_t p = piece + i * kThreads; if (p < n && p < room) dst[p] = src[p]; }
     }
 }
 
 // MUSTAFAR_COMPRESS=twopass keeps the round-2 two-pass form of the fused calls (pass 1 + scan + pass 2); default: one pass.
-int g_compress_form = 0;       // mustafar_compress_set_form: 0 = the process default (environment), 1 = one pass, 2 = two passes
-int g_skip_publish_tb = -1;    // mustafar_compress_test_skip_publish: the NEXT one-pass launch's block of this index does not publish its length (tests)
+// (round 6: both per host THREAD -- a second thread's append neither sees nor resets the form a first thread chose for its repeat, and the
+// test hook is consumed by the thread that armed it)
+thread_local int g_compress_form = 0;       // mustafar_compress_set_form: 0 = the process default (environment), 1 = one pass, 2 = two passes
+thread_local int g_skip_publish_tb = -1;    // mustafar_compress_test_skip_publish: this thread's NEXT one-pass launch's block of this index does not publish its length (tests)
 inline bool one_pass_compress()
 {
     static const int mode = [] { const char* e = getenv("MUSTAFAR_COMPRESS"); return (e && !strcmp(e, "twopass")) ? 0 : 1; }();
@@ -1121,8 +1130,13 @@ int mustafar_compress_set_form(int form)
     return 0;
 }
 
+int mustafar_compress_get_form(void) { return g_compress_form; }
+
 int mustafar_compress_test_skip_publish(int block)
 {
+    // a test hook in the product library: armed only in a process that asked for test hooks before its first use (tests/conftest.py)
+    static const bool hooks = [] { const char* e = getenv("MUSTAFAR_TEST_HOOKS"); return e && *e == '1'; }();
+    if (!hooks) return MUSTAFAR_EINVAL;
     g_skip_publish_tb = block < 0 ? -1 : block;
     return 0;
 }

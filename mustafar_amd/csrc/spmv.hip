@@ -2956,7 +2956,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_leanpair_kernel(
 //   * a pair of waves takes TWO consecutive blocks as one 128-token super-block: key phase A, key phase B, ONE softmax step over the
 //     128 tokens (one maximum per head: one DPP reduction instead of two), value phase A, value phase B.  At four blocks per workgroup
 //     (every BASELINE shape) a pair runs its loop once: no running maximum, no rescale factors, no exchange of them, two barriers per
-//     workgroup instead of four; longer loops keep the online form;
+//     workgroup instead of four (longer loops run decode_onepass_leanpair_kernel);
 //   * the softmax denominator stays per LANE and is summed over the lanes once behind the loop (no DPP reduction in the step);
 //   * one body for both waves of a pair: the odd wave's pointers are biased by its 64 tiles / 64 channels once, in front of the loop, so that
 //     the phase code (lean_block_phase<.., 0, 2>) and every register choice are the same for both -- the phases are in the kernel's text
@@ -3003,7 +3003,8 @@ __device__ __forceinline__ uint32_t ld_at(const void* __restrict__ sbase, uint32
 {
     return *reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(sbase) + voff);
 }
-template <int ENG, bool EXT = false, int G = 4, bool MASK = false, bool MULTI = false>   // MULTI: a pair may walk more than one super-block (the online form)
+template <int ENG, bool EXT = false, int G = 4, bool MASK = false>   // (a pair walks ONE super-block: launches of more than four blocks per workgroup run
+                                                                     // decode_onepass_leanpair_kernel; round 5 carried an uninstantiated online form here -- removed in round 6)
 __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
     const uint64_t* __restrict__ k_bmp, const unsigned char* __restrict__ k_nz, const uint32_t* __restrict__ k_idx,
     const uint32_t* __restrict__ k_nz_off, const uint64_t* __restrict__ v_bmp, const unsigned char* __restrict__ v_nz,
@@ -3013,7 +3014,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
     static_assert(G == 4 || ENG == 0, "dot2 and the matrix pipe work on four heads; G < 4 runs v_fma_mix");
     constexpr int HW = G >= 2 ? G / 2 : 1;   // heads a wave of the pair finishes (G = 1: the even wave its one head, the odd wave none)
     constexpr int kTabBytes = ENG == 1 ? 4 * kKeyTabStride + 2 * 2 * 4 * kValTabStride : 0;   // q rows; per pair TWO e tables (blocks A, B)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes + 2 * G * 4];   // (+ the pairs' rescale factors)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + kTabBytes];
     typedef typename FVec<G>::type fvG;
     typedef typename FVec<HW>::type fvH;
     MUSTAFAR_PTRACE_BEGIN();
@@ -3052,13 +3053,12 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
     }
     const int pair = wave >> 1;
     const int odd = wave & 1;
-    // the pair's blocks: the first pair takes the first half of the workgroup's blocks (rounded up), the second pair the rest; both walk
-    // theirs two at a time, `trips` times (workgroup-uniform: every wave reaches the barriers)
+    // the pair's blocks: the first pair takes the first half of the workgroup's blocks (rounded up), the second pair the rest: at most two
+    // each (the host launches this kernel for tb_per_wg <= 4 only), walked as one super-block
     const int nblk = tb_end - tb0;
     const int nfirst = (nblk + 1) >> 1;
     const int pb0 = tb0 + (pair ? nfirst : 0);
     const int pb_end = pair ? tb_end : tb0 + nfirst;
-    const int trips = (nfirst + 1) >> 1;
     const int64_t tiles = (int64_t)(EXT ? a.nb0 : ntb) * kTilesPerTb;
     const uint64_t* kb;
     const uint32_t* ki;
@@ -3103,7 +3103,6 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
     fvG* xch_out = reinterpret_cast<fvG*>(lds) + lane;                                                       // (+ 64 for block B)
     const float* xch_mine = reinterpret_cast<const float*>(lds) + lane * G + h0;                               // (+ 64 * G for block B)
     const float* xch_part = reinterpret_cast<const float*>(smem + (wave ^ 1) * kStageBytes) + lane * G + h0;
-    float* alf = reinterpret_cast<float*>(smem + kWaves * kStageBytes + kTabBytes) + pair * G;
     constexpr float kEScaleLog2 = ENG == 2 ? 15.f : 0.f;
     // per-lane byte offsets of the two metadata loads of a phase (no address arithmetic at the call sites):
     //   bounds + offset lines: lane k < 3 reads idx[32 k] (the wave's three chunk bounds), lanes 3 / 4 the 64-byte lines in between
@@ -3134,9 +3133,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
     if (late_round) __builtin_amdgcn_s_setprio(3);
     else if (MUSTAFAR_SB_PRIO) __builtin_amdgcn_s_setprio(1);
     asm volatile("; sb_trips_begin");   // (markers for tools/isa_breakdown.py --markers: a comment in the ISA, no instruction)
-#pragma unroll 1
-    for (int trip = 0; trip < (MULTI ? trips : 1); trip++) {
-        const int tA = pb0 + 2 * trip;
+    {
+        const int tA = pb0;
         const bool actA = tA < pb_end, actB = tA + 1 < pb_end;   // (wave-uniform)
         const int tAc = actA ? tA : tb0;                          // (an idle pair addresses the workgroup's first block and computes nothing)
         const int tBc = actB ? tA + 1 : tAc;
@@ -3195,7 +3193,6 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
         if (actA && has_heads) {
             const fvH mineA = *reinterpret_cast<const fvH*>(xch_mine), partA = *reinterpret_cast<const fvH*>(xch_part);
             const fvH mineB = *reinterpret_cast<const fvH*>(xch_mine + 64 * G), partB = *reinterpret_cast<const fvH*>(xch_part + 64 * G);
-            float al[HW] = {};
 #pragma unroll
             for (int j = 0; j < HW; j++) {
                 float pa, pb;
@@ -3215,20 +3212,8 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
                     eA[(h0 + j) * 64 + lane] = ea;
                     if (actB) eB[(h0 + j) * 64 + lane] = eb2;
                 }
-                if constexpr (MULTI) {
-                    if (trip) {   // a later trip of a longer loop: the online form (running maximum, rescaled sums and outputs)
-                        al[j] = uniform_f(__expf(m_run[j] - m_new));
-                        l_lane[j] *= al[j];
-                    }
-                }
                 l_lane[j] += (float)ea + (float)eb2;
                 m_run[j] = m_new;
-            }
-            if constexpr (MULTI) {
-                if (trip) {
-                    if constexpr (HW == 2) { if (lane < 2) alf[h0 + lane] = lane ? al[1] : al[0]; }
-                    else                   { if (lane < 1) alf[h0] = al[0]; }
-                }
             }
             if constexpr (ENG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my e stores have reached L2 before the pair's scalar loads
         }
@@ -3236,16 +3221,6 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
         __syncthreads();
         MUSTAFAR_PTRACE_STAMP(3);
         if (actA) {
-            if constexpr (MULTI) {
-                if (trip) {
-                    const fvG al4 = *reinterpret_cast<const fvG*>(alf);
-#pragma unroll
-                    for (int h = 0; h < G; h++) {
-                        if constexpr (G == 1) acc[h] *= al4;
-                        else                  acc[h] *= al4[h];
-                    }
-                }
-            }
             // (the partner read my outgoing partial scores before the barrier above; my value phase now rewrites the window)
             if (actB) {
                 uint32_t pfVB = 0;
@@ -3836,7 +3811,7 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
 
 extern "C" {
 
-int mustafar_abi_version(void) { return 105; }   // 105 (round 5): mustafar_profile_end2, mustafar_convert_*, mustafar_cache_consolidate_extents, mustafar_compress_set_form
+int mustafar_abi_version(void) { return 106; }   // 106 (round 6): mustafar_compress_get_form; the compression form and the test hook are per host thread; 105 (round 5): mustafar_profile_end2, mustafar_convert_*, mustafar_cache_consolidate_extents, mustafar_compress_set_form
 
 int Key_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const void* NZ, const uint32_t* idx,
                    const uint32_t* NZ_offset, const void* B, void* C, int M_Global, int N_Global, int K_Global,

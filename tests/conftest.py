@@ -8,6 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the product library arms its one test hook (mustafar_compress_test_skip_publish) only in a process that asks for it before first use
+os.environ.setdefault("MUSTAFAR_TEST_HOOKS", "1")
 
 
 def pytest_configure(config):

@@ -34,6 +34,8 @@ CASES = {  # BASELINE.json configs[1..4]: (Hq, Hkv, sparsity, L, batch)
     "c4": (32, 8, 0.8, 32768, 4),
     "c5": (32, 8, 0.7, 16384, 16),
     "g2": (32, 16, 0.7, 4096, 4),      # GQA-2 at size: the G = 2 instantiation of the pair kernel (round 4)
+    "m8": (32, 32, 0.7, 8192, 8),      # MHA at size (round 6): 32 / 32 heads, L = 8192, batch 8 -- four blocks per workgroup on the G = 1 form, the shape
+                                       # round 5's first super-block build got wrong (block B's e segments read at G = 4's offset) while every suite case passed
     "s4": (32, 8, 0.7, 4096, 8),
     "s32": (32, 8, 0.7, 32768, 8),
     "c3w": (32, 8, 0.7, 7936 + 32 + 255, 8),   # c3's geometry with a window one token short of the trigger (round 5: off the grid of whole rounds)
@@ -93,7 +95,7 @@ def _new(batch, Hq, Hkv):
             torch.randn(batch, Hkv, 1, 128, device=DEV).half())
 
 
-@pytest.mark.parametrize("name,structure", [("c2", 2), ("c3", 2), ("c4", 2), ("c5", 2), ("s4", 2), ("s32", 2), ("g2", 2), ("c3", 0), ("c5", 1)])
+@pytest.mark.parametrize("name,structure", [("c2", 2), ("c3", 2), ("c4", 2), ("c5", 2), ("s4", 2), ("s32", 2), ("g2", 2), ("m8", 2), ("c3", 0), ("c5", 1)])
 def test_fused_arena_eager_and_graph_at_bench_shape(name, structure):
     """structure 2 = the library's own choice by size (the one-pass launch at every config since round 3); the two-launch
     structure is forced once at c3, the one-pass launch named explicitly once at c5."""
@@ -265,7 +267,7 @@ def test_a_dropped_block_fails_the_comparators_at_c4():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5", "s4", "s32"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c5", "s4", "s32", "m8"])
 def test_one_head_at_full_length_against_the_c_oracle(name):
     """The CPU oracle finishes one kv-head at full T in seconds: prune, compress and both SpMVs of that head, HIP vs C."""
     from mustafar_amd import compression, mustafar_package as mp

@@ -51,7 +51,7 @@ tools/prof_cfgs.sh "c3 t8192 t8448 t8704" > $O/offgrid_kernel_stats.txt 2> $O/of
 python3 tools/bench_extent_append.py 2> $O/extent_append.err > $O/extent_append.txt; nonempty $O/extent_append.txt
 # round 5: the instruction classes of the timed kernel's ISA (static; tools/isa_breakdown.py) next to the counters
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 -S --cuda-device-only -o /tmp/spmv_isa.s mustafar_amd/csrc/spmv.hip 2> /dev/null
-{ echo "== decode_onepass_sb_kernel<2, false, 4, false, false> (dot2; the timed kernel): text between the trip markers holds the two-block pipelines AND the one-block alternatives: 384 tiles of text for the 256 a wave walks"; python3 tools/isa_breakdown.py /tmp/spmv_isa.s 'decode_onepass_sb_kernelILi2ELb0ELi4ELb0ELb0E' --tiles 384 --markers;
+{ echo "== decode_onepass_sb_kernel<2, false, 4, false> (dot2; the timed kernel): text between the trip markers holds the two-block pipelines AND the one-block alternatives: 384 tiles of text for the 256 a wave walks"; python3 tools/isa_breakdown.py /tmp/spmv_isa.s 'decode_onepass_sb_kernelILi2ELb0ELi4ELb0EE' --tiles 384 --markers;
   echo; echo "== decode_onepass_leanpair_kernel<2, false, 4> (round 4's kernel: one trip of its block loop, the even wave's path, 128 tiles)"; python3 tools/isa_breakdown.py /tmp/spmv_isa.s 'decode_onepass_leanpair_kernelILi2ELb0ELi4E'; } > $O/isa_breakdown.txt; nonempty $O/isa_breakdown.txt
 # only the summaries travel back (gpurun merges at most 64 MiB): the profiler's raw directories are dropped
 rm -rf $R/gpurun_out/pmc_${TAG}_* $R/gpurun_out/traffic_${TAG}_* $O/rocprof_bench
