@@ -479,6 +479,47 @@ class Workload:
         del state
         return dt, kern
 
+    def fixed_graph(self):
+        """The fused step of all layers captured with NO counter step behind it: every replay is the SAME step -- same compressed length, same
+        window length, the newest row stored over itself -- for as long as one likes (no trigger is ever reached).  -> (graph, outputs, state)"""
+        attn, qs, ks, vs, layers, dev = self.attn, self.qs, self.ks, self.vs, self.layers, self.dev
+        state = self.fused_state()
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        warm = (state[0][0], state[0][1].clone(), state[0][2], state[0][3].clone(), state[0][4], state[0][5])
+        attn.decode_fused(qs[0], ks[0], vs[0], warm)              # allocates the scratch buffers outside the capture
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outs = [attn.decode_fused(qs[l], ks[l], vs[l], state[l], step_counter=counter)[0] for l in range(layers)]
+        return g, outs, state
+
+    def timed_sustained(self, steps, warmup=5, windows=8):
+        """>= 200 replays of the step at FIXED compressed length and window length (no trigger, nothing grows): the rate the device holds once
+        the first ~30 ms are over, next to the 20-step headline.  Also the course of it: ms/step over `windows` equal stretches (HIP events
+        between replays, on the stream the graph is launched on)."""
+        g, _, state = self.fixed_graph()
+        dev = self.dev
+        for _ in range(warmup):
+            g.replay()
+        per = max(1, steps // windows)
+        evs = []
+
+        def run():
+            for i in range(steps):
+                if i % per == 0:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(torch.cuda.current_stream(dev))
+                    evs.append(e)
+                g.replay()
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(dev))
+            evs.append(e)
+        dt = self.bracket(run)
+        marks = [i for i in range(steps) if i % per == 0] + [steps]
+        course = [round(evs[i].elapsed_time(evs[i + 1]) / (marks[i + 1] - marks[i]), 4) for i in range(len(evs) - 1)]
+        del state
+        return dt, course
+
     def roofline(self, key_us, val_us, n, traffic_file=True):
         """Roofline object of the dominant kernel.  One-pass form (val_us == 0): ONE launch does the key phase, the softmax
         step and the value phase; its algorithmic bytes are those of the two SpMVs together (the e rows it writes

@@ -66,15 +66,18 @@ struct WaveTrace {
 #define MUSTAFAR_TRACE_END() wave_trace_.end()
 // One-pass launches (tools/wave_trace_onepass.py): 16 x u64 per wave -- t[0] start, t[1] first key chunk staged, t[2] key phase
 // done, t[3] softmax step done, t[4] first value chunk staged, t[5] value phase done (all of the wave's FIRST block), t[6] end;
-// [8] HW_ID / XCC_ID, [9] grid position, [10] valid.  Slot = the wave's linear grid position.
+// [8] HW_ID / XCC_ID, [9] grid position, [10] valid, [11] / [12] the SHADER clock (s_memtime) next to t[0] / t[6]: the wave's in-kernel clock is
+// ([12] - [11]) / (t[6] - t[0]) x 100 MHz (round 6, tools/clock_probe.py; MI355X_MICROARCH.md, DVFS give-back (6)).  Slot = the wave's linear grid position.
 struct PhaseTrace {
     unsigned long long t[7];
-    __device__ PhaseTrace() { t[0] = __builtin_amdgcn_s_memrealtime(); for (int i = 1; i < 7; i++) t[i] = 0; }
+    unsigned long long c0;
+    __device__ PhaseTrace() { t[0] = __builtin_amdgcn_s_memrealtime(); c0 = __builtin_amdgcn_s_memtime(); for (int i = 1; i < 7; i++) t[i] = 0; }
     __device__ void stamp(int i) { if (t[i] == 0) t[i] = __builtin_amdgcn_s_memrealtime(); }
     __device__ void end(unsigned int kernel)
     {
         if (g_trace_buf == nullptr || (threadIdx.x & 63) != 0) return;
         t[6] = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
         const unsigned int w = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (w >= g_trace_cap / 4) return;
         const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
@@ -83,6 +86,8 @@ struct PhaseTrace {
         r[8] = ((unsigned long long)xcc << 32) | hw;
         r[9] = ((unsigned long long)kernel << 56) | ((unsigned long long)(threadIdx.x >> 6) << 48) | ((unsigned long long)blockIdx.y << 24) | blockIdx.x;
         r[10] = 1;
+        r[11] = c0;
+        r[12] = c1;
     }
 };
 #define MUSTAFAR_PTRACE_BEGIN() PhaseTrace phase_trace_
@@ -2168,12 +2173,23 @@ __device__ __forceinline__ void gather2_wait(Gathered2& g, u32x4 (&c)[4])   // d
 #define MUSTAFAR_DOT4(p, w)                                                                                          \
     "v_dot2_f32_f16 %[a0], %[t" #p "], %[c0" #w "], %[a0]\n\tv_dot2_f32_f16 %[a1], %[t" #p "], %[c1" #w "], %[a1]\n\t"   \
     "v_dot2_f32_f16 %[a2], %[t" #p "], %[c2" #w "], %[a2]\n\tv_dot2_f32_f16 %[a3], %[t" #p "], %[c3" #w "], %[a3]\n\t"
+// DOT hazard of gfx90a / gfx940 / gfx950 (LLVM GCNHazardRecognizer::checkMAIVALUHazards: DotWriteDifferentVALURead = 3,
+// DotWriteDifferentVALUWrite = 4): the result of a v_dot2 may be READ by a different vector instruction only 3 wait states later and
+// its register be WRITTEN by one only 4 later (the same dot opcode accumulating into it back to back is fine).  The compiler inserts
+// those wait states for its own instructions; it cannot see a v_dot2 inside an asm statement, so the statement itself ends with them.
+// Round 6 found this the hard way: with the online-softmax text removed the register allocator placed `v_mov_b32 v29, v9` one wait
+// state behind the key phase's last `v_dot2_f32_f16 v9, ...` and half of the block pairs got a stale partial score for head 3 (the
+// LAST accumulator written) -- bisected on the ISA with tools/isa_patch.sh (profiles/r06_probes.txt item 1); 16 wait states in front of
+// that move fixed it, this is the principled form.  tools/check_smem_hazards.py check (6) holds every asm statement to it.
+#ifndef MUSTAFAR_DOT_GUARD
+#define MUSTAFAR_DOT_GUARD "s_nop 3\n\t"
+#endif
 // acc[h] += tile(2w) * coef(2w) + tile(2w + 1) * coef(2w + 1): the coefficient dword w of head h holds exactly that pair
 __device__ __forceinline__ void fma8_d2(const u32x4 (&c)[4], Gathered2& g, float (&acc)[4])
 {
     asm volatile("v_or_b32 %[t0], %[t0], %[t1]\n\tv_or_b32 %[t2], %[t2], %[t3]\n\t"
                  "v_or_b32 %[t4], %[t4], %[t5]\n\tv_or_b32 %[t6], %[t6], %[t7]\n\t"
-                 MUSTAFAR_DOT4(0, 0) MUSTAFAR_DOT4(2, 1) MUSTAFAR_DOT4(4, 2) MUSTAFAR_DOT4(6, 3)
+                 MUSTAFAR_DOT4(0, 0) MUSTAFAR_DOT4(2, 1) MUSTAFAR_DOT4(4, 2) MUSTAFAR_DOT4(6, 3) MUSTAFAR_DOT_GUARD
                  : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [t0] "+v"(g.t[0]), [t2] "+v"(g.t[2]),
                    [t4] "+v"(g.t[4]), [t6] "+v"(g.t[6])
                  : [t1] "v"(g.t[1]), [t3] "v"(g.t[3]), [t5] "v"(g.t[5]), [t7] "v"(g.t[7]), MUSTAFAR_COPS(0), MUSTAFAR_COPS(1),
@@ -2236,7 +2252,7 @@ __device__ __forceinline__ void gather2u_wait(Gathered2u& g, u32x4 (&c)[4])   //
 __device__ __forceinline__ void fma8_d2s(const u32x4 (&c)[4], Gathered2u& g, uint32_t zero, float (&acc)[4])
 {
     asm volatile(MUSTAFAR_D2S_PAIR(0, 1) MUSTAFAR_D2S_PAIR(2, 3) MUSTAFAR_DOT4(0, 0) MUSTAFAR_D2S_PAIR(4, 5) MUSTAFAR_DOT4(2, 1)
-                 MUSTAFAR_D2S_PAIR(6, 7) MUSTAFAR_DOT4(4, 2) "s_nop 0\n\t" MUSTAFAR_DOT4(6, 3)
+                 MUSTAFAR_D2S_PAIR(6, 7) MUSTAFAR_DOT4(4, 2) "s_nop 0\n\t" MUSTAFAR_DOT4(6, 3) MUSTAFAR_DOT_GUARD
                  : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [t0] "+v"(g.t[0]), [t2] "+v"(g.t[2]),
                    [t4] "+v"(g.t[4]), [t6] "+v"(g.t[6])
                  : [t1] "v"(g.t[1]), [t3] "v"(g.t[3]), [t5] "v"(g.t[5]), [t7] "v"(g.t[7]), [z] "v"(zero),

@@ -11,7 +11,8 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 NAME="$1"; shift
-CANNOT_FAULT="MUSTAFAR_PROBE_NOLDSWAIT"   # the FMAs do not wait for the gathered values / coefficients: stale OPERANDS, no address
+CANNOT_FAULT="MUSTAFAR_PROBE_NOLDSWAIT MUSTAFAR_DOT_GUARD"   # stale OPERANDS of arithmetic, never an address: the FMAs not waiting for the gathered values /
+                                                           # coefficients; the wait states behind a v_dot2 left out (timing A/B of the guard itself)
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function)
 TMP="$(mktemp -d)"; trap 'rm -rf "$TMP"' EXIT
 hipcc "${FLAGS[@]}" "$@" --cuda-device-only -S -I"$ROOT/include" -o "$TMP/spmv.s" "$ROOT/mustafar_amd/csrc/spmv.hip"

@@ -22,6 +22,14 @@ the restoring -1 would switch lanes on that the program had switched off.
 register per kernel that the compiler does not know is pending; all of a kernel's sink loads must name the same register and no
 other instruction of the kernel may write it.
 
+(6) DOT hazard (round 6).  On gfx90a / gfx940 / gfx950 the result of a v_dot* instruction may be read by a DIFFERENT vector instruction only
+3 wait states later, and its register be written by one only 4 later (LLVM GCNHazardRecognizer: DotWriteDifferentVALURead /
+DotWriteDifferentVALUWrite).  The compiler pads its own instructions; it cannot see a v_dot2 inside an asm statement -- and it does place
+moves of the accumulators right behind such a statement (round 6: `v_mov_b32 v29, v9` one wait state behind the key phase's last
+`v_dot2_f32_f16 v9`: half the block pairs got a stale score for one head).  So: every asm statement that contains a v_dot* must end with
+at least 4 wait states behind its last v_dot* (instructions that do not touch the dot's destination count one each, `s_nop N` counts N + 1),
+and inside a statement a non-dot vector instruction may not read / write a dot's destination 3 / 4 wait states or less behind it.
+
 (5) No private segment on the hot launches (round 5).  A kernel with a private segment -- a vector spill, or only the compiler's
 emergency slot with no scratch instruction in the text -- is launched with scratch; the key entry point lost 8-10 % to one that a
 branch it never takes (the fused decode's window workgroups) had brought in.  The kernels a default call reaches -- every
@@ -268,6 +276,48 @@ _SCRATCH_FREE = (r"decode_onepass_sb_kernel", r"onepass_finish_kernel", r"key_le
                  r"value_spmv_kernelILi\dELb[01]ELi\dELi\dELb0E", r"value_combine_kernel")
 
 
+def check_dot_hazards(asm_text):
+    """Check (6): [(kernel, line, text)] of asm statements whose v_dot* results are not covered by the wait states the hardware needs."""
+    bad, n_dots = [], 0
+    for kernel, ins in _kernels(asm_text):
+        in_asm = False
+        recent = []          # [(dest vgprs, wait states since, line, code)] of dots inside the current statement
+        for ln, code, _ in ins:
+            if code == "#ASMSTART":
+                in_asm, recent = True, []
+                continue
+            if code == "#ASMEND":
+                for dest, ws, l0, c0 in recent:
+                    if ws < 4:
+                        bad.append((kernel, l0, c0 + f"   <- only {ws} wait state(s) to the end of its asm statement"))
+                in_asm, recent = False, []
+                continue
+            if not in_asm or code.startswith(".") or code.startswith("#"):
+                continue
+            parts = code.replace(",", " ").split()
+            op, args = parts[0], parts[1:]
+            if op.startswith("v_dot"):
+                n_dots += 1
+                # (the same dot opcode accumulating into the register -- SrcC -- is fine back to back; as SrcA / SrcB it is not)
+                for dest, ws, l0, c0 in recent:
+                    if ws < 3 and args[1:3] and (vgprs(args[1]) | vgprs(args[2])) & dest:
+                        bad.append((kernel, ln, code + "   <- reads a dot result as a factor too early"))
+                recent = [(d, w + 1, l0, c0) for d, w, l0, c0 in recent]
+                recent.append((vgprs(args[0]), 0, ln, code))
+                continue
+            step = 1
+            if op == "s_nop":
+                step = int(args[0], 0) + 1
+            elif op.startswith("v_"):
+                rd = set().union(*[vgprs(x) for x in args[1:]]) if len(args) > 1 else set()
+                wr = vgprs(args[0]) if args else set()
+                for dest, ws, l0, c0 in recent:
+                    if (rd & dest and ws < 3) or (wr & dest and ws < 4):
+                        bad.append((kernel, ln, code + f"   <- touches the result of `{c0}` {ws} wait state(s) behind it"))
+            recent = [(d, w + step, l0, c0) for d, w, l0, c0 in recent]
+    return bad, n_dots
+
+
 def check_private_segments(asm_text):
     """Check (5): [(kernel, bytes of private segment, vector spills)] of the hot kernels that have either."""
     bad, seen = [], 0
@@ -303,7 +353,11 @@ def main(asm_file=None, faults_only=False):
     print(f"scalar loads: {loads}, draining waits: {waits}, EXEC-masked stretches restored: {stretches}, prefetch sink loads: {sinks}, hazards: {len(hazards)}")
     for k, ln, code in hazards[:20]:
         print(f"  {k}: line {ln}: {code}")
-    if hazards:
+    dots, n_dots = check_dot_hazards(text)
+    print(f"v_dot* inside asm statements: {n_dots}, uncovered dot results: {len(dots)}")
+    for k, ln, code in dots[:20]:
+        print(f"  {k}: line {ln}: {code}")
+    if hazards or dots:
         return 1
     return 0 if faults_only else _report_private(text)
 
