@@ -58,6 +58,7 @@ CONFIGS["t8448"] = ("Llama-3-8B 70% T=8448 b8 [tools only]", 32, 8, 0.7, 8448 + 
 for _t in (8704, 8960, 9216, 9728, 10240, 12288):   # (off the grid of whole rounds of workgroups: tools/quick.py, the `seq_offgrid` leg)
     CONFIGS[f"t{_t}"] = (f"Llama-3-8B 70% T={_t} b8 [tools only]", 32, 8, 0.7, _t + 32, 8)
 CONFIGS["b1"] = ("Llama-3-8B 70% L=8192 b1 [tools only]", 32, 8, 0.7, 8192, 1)
+CONFIGS["b1s"] = ("Llama-3-8B 70% L=4096 b1 [tools only]", 32, 8, 0.7, 4096, 1)
 CONFIGS["b1l"] = ("Llama-3-8B 70% L=32768 b1 [tools only]", 32, 8, 0.7, 32768, 1)
 CONFIGS["m8"] = ("Llama-2-7B (MHA) 70% L=8192 b8 [tools only]", 32, 32, 0.7, 8192, 8)
 CONFIGS["g2"] = ("GQA-2 (32 q / 16 kv heads) 70% L=8192 b8 [tools only]", 32, 16, 0.7, 8192, 8)
@@ -529,7 +530,7 @@ class Workload:
             # which one-pass kernel ran (the last fused call on this thread was the eager pass that took these timestamps)
             ch = self.lib.mustafar_last_decode_choice()
             eng, form = ch & 15, (ch >> 8) & 15
-            dom = {3: f"decode_onepass_sb_kernel<{eng}>", 2: f"decode_onepass_leanpair_kernel<{eng}>", 1: f"decode_onepass_lean_kernel<{eng}>"}.get(
+            dom = {4: f"decode_onepass_small_kernel<{eng}>", 3: f"decode_onepass_sb_kernel<{eng}>", 2: f"decode_onepass_leanpair_kernel<{eng}>", 1: f"decode_onepass_lean_kernel<{eng}>"}.get(
                 form, "decode_onepass_kernel<G, matrix pipe>" if eng == 1 else "decode_onepass_kernel<G, v_fma_mix, pair>")
             dom_us, oth_us = key_us, None
             dom_bytes = self.alg_key + self.alg_val

@@ -337,7 +337,7 @@ int mustafar_get_fma_engine(void);
 int mustafar_set_onepass(int mode);
 int mustafar_get_onepass(void);
 /* What the last fused call on the calling thread launched: FMA engine that ran (0 v_fma_mix_f32, 1 matrix pipe, 2 v_dot2_f32_f16)
- * | structure << 4 (0 two launches, 1 one-pass) | one-pass form << 8 (0 round-2 forms, 1 lean whole-block, 2 lean pair grain, 3 super-block pair form: round 5, the default);
+ * | structure << 4 (0 two launches, 1 one-pass) | one-pass form << 8 (0 round-2 forms, 1 lean whole-block, 2 lean pair grain, 3 super-block pair form: round 5, the default from 768 workgroups on, 4 the small-launch form: round 6, the default below that);
  * -1 before the first call.  For tests and tools: a call's `flags` and the process defaults can be checked against what ran. */
 int mustafar_last_decode_choice(void);
 /* Tuning knobs for the measurement scripts under tools/ (launch shapes of the one-pass forms); not an operator interface. */

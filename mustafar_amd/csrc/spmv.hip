@@ -3290,6 +3290,299 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
     MUSTAFAR_PTRACE_END(7);
 }
 
+// ------------------------------------------------------------------------------------------------ one-pass decode, SMALL launches (round 6)
+// decode_onepass_sb_kernel for launches of two blocks per workgroup (under 768 workgroups: Llama-3-8B 8k x batch 1, c2) -- the same grid, slabs,
+// window workgroups and row kernel.  Such a launch has ~2 waves per SIMD and nothing to hide a latency behind: a wave's life is a chain of
+// dependent round trips (wave timeline at batch 1, us: 2.3 to the first key chunk, 2.7 key steps, 0.7 softmax, 0.7 to the first value chunk,
+// 3.4 value steps, 0.9 merge; profiles/r06_wave_trace_b1.txt), every step of a phase waiting once for its scalar loads (metadata of the next
+// step, coefficients) and once for its gathers.  Here the chain is cut to TWO trips to memory per wave, and no step waits for memory at all:
+//   trip 1 (everything whose address does not depend on data, all at once): the wave's 64 key and 64 value bitmaps and offsets as VECTOR
+//           loads (lane = tile: 8 + 4 bytes per lane and side), the offsets that close the two halves, the q rows (2 dwords per lane), the mask;
+//   trip 2: the four stream chunks of the wave's block -- key 0 / 1 AND value 0 / 1 -- into 64 registers (the launch is compiled for four waves
+//           per SIMD: 128 registers), as soon as the offsets have landed;
+//   steps : a step's bitmaps, offsets and coefficients come out of those registers with v_readlane (24 + 4 G per step: vector issue is idle
+//           in a launch like this), so the only wait of a step is the one for its own LDS gathers;
+//   e     : crosses the pair through an LDS table ([G][64] halfs per pair) instead of a store / vmcnt(0) / scalar-load round trip through L2.
+// One block per pair (a.tb_per_wg == 2), G = 4 on dot2 or v_fma_mix, G = 2 / 1 on v_fma_mix.  mustafar_tune(11, 0) selects the super-block kernel.
+template <int L>
+__device__ __forceinline__ uint32_t rl_at(uint32_t v)   // v_readlane with a constant lane, pinned where it is written (asm volatile keeps the order
+{                                                       // of these statements and of the asm helpers that consume the scalars)
+    uint32_t r;
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(r) : "v"(v), "i"(L));
+    return r;
+}
+// bitmaps / offsets of the 8 tiles [T0, T0 + 8) of the wave's 64 (lane = tile) -> the scalar image the gather helpers take
+template <int T0>
+__device__ __forceinline__ void metab_from_lanes(MetaB& m, uint32_t bm_lo, uint32_t bm_hi, uint32_t ix)
+{
+#define MUSTAFAR_ML(j)                          \
+    m.bm[2 * j] = rl_at<T0 + j>(bm_lo);         \
+    m.bm[2 * j + 1] = rl_at<T0 + j>(bm_hi);     \
+    m.ix[j] = rl_at<T0 + j>(ix);
+    MUSTAFAR_ML(0) MUSTAFAR_ML(1) MUSTAFAR_ML(2) MUSTAFAR_ML(3) MUSTAFAR_ML(4) MUSTAFAR_ML(5) MUSTAFAR_ML(6) MUSTAFAR_ML(7)
+#undef MUSTAFAR_ML
+}
+// coefficients of step D0 / 4 (dwords [D0, D0 + 4) of every head's 32): cv[r] lane (h & 1) * 32 + d holds dword d of head 2 r + (h & 1)
+template <int G, int D0>
+__device__ __forceinline__ void coef_from_lanes(u32x4 (&c)[G], const uint32_t (&cv)[(G + 1) / 2])
+{
+#define MUSTAFAR_CL(h, r, base)          \
+    c[h][0] = rl_at<base + D0>(cv[r]);   \
+    c[h][1] = rl_at<base + D0 + 1>(cv[r]); \
+    c[h][2] = rl_at<base + D0 + 2>(cv[r]); \
+    c[h][3] = rl_at<base + D0 + 3>(cv[r]);
+    MUSTAFAR_CL(0, 0, 0)
+    if constexpr (G >= 2) { MUSTAFAR_CL(1, 0, 32) }
+    if constexpr (G == 4) { MUSTAFAR_CL(2, 1, 0) MUSTAFAR_CL(3, 1, 32) }
+#undef MUSTAFAR_CL
+    // a vector instruction may read a scalar register a vector instruction wrote only 2 wait states later (gfx940+); the consumers sit in asm
+    // statements the compiler does not look into
+    asm volatile("s_nop 1");
+}
+template <int ENG, int G, int T0>   // the 8 tiles [T0, T0 + 8) of the wave's 64 against coefficient dwords [T0 / 2, T0 / 2 + 4) of every head
+__device__ __forceinline__ void small_step(uint32_t adj, uint32_t bm_lo, uint32_t bm_hi, uint32_t ix, const uint32_t (&cv)[(G + 1) / 2], float (&acc)[G])
+{
+    MetaB m;
+    u32x4 c[G];
+    metab_from_lanes<T0>(m, bm_lo, bm_hi, ix);
+    coef_from_lanes<G, T0 / 2>(c, cv);
+    if constexpr (ENG == 2) {
+        Gathered2 g;
+        gather8_d2(m, adj, g);
+        gather2_wait(g, c);
+        fma8_d2(c, g, acc);
+    } else {
+        Gathered g;
+        gather8(m, adj, g);
+        gather_wait<G>(g, c);
+        fma8<G>(c, g, acc);
+    }
+}
+// the wave's 64 tiles of one side of its block: chunk 0 (tiles 0..31, stream offsets [i0, i1)) and chunk 1 (tiles 32..63, [i1, ...)), both
+// already in registers
+template <int ENG, int G>
+__device__ __forceinline__ void small_phase(unsigned char* lds, uint32_t lds_addr, int lane, const Stage& s0, const Stage& s1, uint32_t i0, uint32_t i1,
+                                            uint32_t bm_lo, uint32_t bm_hi, uint32_t ix, const uint32_t (&cv)[(G + 1) / 2], float (&acc)[G])
+{
+    stage_commit(lds, s0, lane, 4096u);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t adj0 = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i0);
+    small_step<ENG, G, 0>(adj0, bm_lo, bm_hi, ix, cv, acc);
+    small_step<ENG, G, 8>(adj0, bm_lo, bm_hi, ix, cv, acc);
+    small_step<ENG, G, 16>(adj0, bm_lo, bm_hi, ix, cv, acc);
+    small_step<ENG, G, 24>(adj0, bm_lo, bm_hi, ix, cv, acc);
+    __builtin_amdgcn_wave_barrier();
+    stage_commit(lds, s1, lane, 4096u);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t adj1 = __builtin_amdgcn_readfirstlane(lds_addr - 4u * i1);
+    small_step<ENG, G, 32>(adj1, bm_lo, bm_hi, ix, cv, acc);
+    small_step<ENG, G, 40>(adj1, bm_lo, bm_hi, ix, cv, acc);
+    small_step<ENG, G, 48>(adj1, bm_lo, bm_hi, ix, cv, acc);
+    small_step<ENG, G, 56>(adj1, bm_lo, bm_hi, ix, cv, acc);
+    __builtin_amdgcn_wave_barrier();
+}
+template <int ENG, bool EXT = false, int G = 4, bool MASK = false>
+__global__ __launch_bounds__(kThreads, 4) void decode_onepass_small_kernel(
+    const uint64_t* __restrict__ k_bmp, const unsigned char* __restrict__ k_nz, const uint32_t* __restrict__ k_idx,
+    const uint32_t* __restrict__ k_nz_off, const uint64_t* __restrict__ v_bmp, const unsigned char* __restrict__ v_nz,
+    const uint32_t* __restrict__ v_idx, const uint32_t* __restrict__ v_nz_off, OneArgs a, int64_t k_bmp_stride,
+    int64_t k_idx_stride, uint32_t k_nz_stride, int64_t v_bmp_stride, int64_t v_idx_stride, uint32_t v_nz_stride)
+{
+    static_assert(ENG == 0 || (ENG == 2 && G == 4), "v_fma_mix for every group count, dot2 for four heads (the matrix-pipe engine keeps the super-block kernel)");
+    constexpr int HW = G >= 2 ? G / 2 : 1;   // heads a wave of the pair finishes (G = 1: the even wave its one head, the odd wave none)
+    constexpr int NR = (G + 1) / 2;          // coefficient registers: two heads of 32 dwords each per register
+    constexpr int kETab = G * 64 * 2;        // bytes of a pair's e table
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWaves * kStageBytes + 2 * kETab];
+    typedef typename FVec<G>::type fvG;
+    typedef typename FVec<HW>::type fvH;
+    MUSTAFAR_PTRACE_BEGIN();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wrows = a.win_rows < 0 ? -a.win_rows : a.win_rows;
+    const int wy = a.win_rows < 0 ? (int)blockIdx.y - ((int)gridDim.y - wrows) : (int)blockIdx.y;
+    if (wy >= 0 && wy < wrows) {   // dense window (as decode_onepass_sb_kernel)
+        const int task = wy * gridDim.x + blockIdx.x;
+        if (task < (int)(gridDim.y - wrows) * a.nchunks) {
+            int T_used = -1;
+            if constexpr (EXT) { if (a.t_dev) T_used = __builtin_amdgcn_readfirstlane(*a.t_dev); }
+            onepass_window_wg<G>(smem, win_args(a, T_used), task, gridDim.x);
+        }
+        MUSTAFAR_PTRACE_END(5);
+        return;
+    }
+    const int by = blockIdx.y - (a.win_rows > 0 ? a.win_rows : 0);
+    const int hb_per_kv = a.groups / G;
+    const int kvh = hb_per_kv == 1 ? by : by / hb_per_kv;
+    const int bh0 = kvh * a.groups + (by - kvh * hb_per_kv) * G;
+    const int ntb_cap = a.T >> 6;
+    int ntb = ntb_cap;
+    if constexpr (EXT) { if (a.t_dev) ntb = min(ntb_cap, __builtin_amdgcn_readfirstlane(*a.t_dev) >> 6); }
+    const int tb0 = blockIdx.x * 2;   // (the host launches this kernel for two blocks per workgroup only)
+    if constexpr (EXT) {
+        if (tb0 >= ntb) {   // a workgroup beyond the tokens in use: a slab of weight zero (as decode_onepass_sb_kernel)
+            float* so = a.ws_o + ((int64_t)blockIdx.x * a.BH + bh0) * kD;
+#pragma unroll
+            for (int o = 0; o < G * kD; o += kThreads) so[o + (threadIdx.x & (G * kD - 1) & (kThreads - 1))] = 0.f;
+            *reinterpret_cast<float2*>(a.ws_ml + ((int64_t)blockIdx.x * a.BH + bh0 + (threadIdx.x & (G - 1))) * 2) = make_float2(-INFINITY, 0.f);
+            return;
+        }
+    }
+    const int pair = wave >> 1;
+    const int odd = wave & 1;
+    const int t = tb0 + pair;            // the pair's block
+    const bool act = t < ntb;            // (wave-uniform; an idle pair addresses the workgroup's first block and computes nothing)
+    const int tc = act ? t : tb0;
+    const int64_t tiles = (int64_t)(EXT ? a.nb0 : ntb) * kTilesPerTb;
+    const uint64_t* kb;
+    const uint32_t* ki;
+    const unsigned char* kn;
+    const uint64_t* vb;
+    const uint32_t* vi;
+    const unsigned char* vn;
+    if (EXT && tb0 >= a.nb0) {
+        const int e = (tb0 - a.nb0) >> 2;
+        const mustafar_cache_view ek = a.k_ext[e], ev = a.v_ext[e];
+        const int64_t t0 = (int64_t)(a.nb0 + 4 * e) * kTilesPerTb;
+        kb = uniform_ptr(ek.bmp + (int64_t)kvh * ek.bmp_head_stride - t0);
+        ki = uniform_ptr(ek.idx + (int64_t)kvh * ek.idx_head_stride - t0);
+        kn = uniform_ptr(static_cast<const unsigned char*>(ek.nz) + 16ull * (uint64_t)kvh * (uint64_t)ek.nz_head_stride);
+        vb = uniform_ptr(ev.bmp + (int64_t)kvh * ev.bmp_head_stride - t0);
+        vi = uniform_ptr(ev.idx + (int64_t)kvh * ev.idx_head_stride - t0);
+        vn = uniform_ptr(static_cast<const unsigned char*>(ev.nz) + 16ull * (uint64_t)kvh * (uint64_t)ev.nz_head_stride);
+    } else {
+        kb = k_bmp + (int64_t)kvh * (k_bmp_stride ? k_bmp_stride : tiles);
+        ki = k_idx + (int64_t)kvh * (k_idx_stride ? k_idx_stride : tiles + 1);
+        kn = k_nz + 16ull * (k_nz_stride ? (uint64_t)kvh * k_nz_stride : (uint64_t)k_nz_off[kvh]);
+        vb = v_bmp + (int64_t)kvh * (v_bmp_stride ? v_bmp_stride : tiles);
+        vi = v_idx + (int64_t)kvh * (v_idx_stride ? v_idx_stride : tiles + 1);
+        vn = v_nz + 16ull * (v_nz_stride ? (uint64_t)kvh * v_nz_stride : (uint64_t)v_nz_off[kvh]);
+    }
+    // the wave's 64 tiles of either side: tiles odd * 64 ... + 63 of the block
+    const uint64_t* kbT = kb + (int64_t)tc * kTilesPerTb + odd * 64;
+    const uint32_t* kiT = ki + (int64_t)tc * kTilesPerTb + odd * 64;
+    const uint64_t* vbT = vb + (int64_t)tc * kTilesPerTb + odd * 64;
+    const uint32_t* viT = vi + (int64_t)tc * kTilesPerTb + odd * 64;
+    unsigned char* lds = smem + wave * kStageBytes;
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    h16* etab = reinterpret_cast<h16*>(smem + kWaves * kStageBytes + pair * kETab);   // [G][64] halfs
+    const int h0 = (odd && G >= 2) ? HW : 0;
+    const bool has_heads = G >= 2 || !odd;
+    fvG* xch_out = reinterpret_cast<fvG*>(lds) + lane;
+    const float* xch_mine = reinterpret_cast<const float*>(lds) + lane * G + h0;
+    const float* xch_part = reinterpret_cast<const float*>(smem + (wave ^ 1) * kStageBytes) + lane * G + h0;
+    constexpr float kEScaleLog2 = ENG == 2 ? 15.f : 0.f;
+
+    // ---- trip 1: offsets first (the streams hang on them), then bitmaps, q rows, mask
+    const uint32_t kix = kiT[lane], kie = kiT[64], vix = viT[lane], vie = viT[64];
+    const uint64_t kbm = kbT[lane], vbm = vbT[lane];
+    uint32_t qv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int h = 2 * r + (lane >> 5);
+        qv[r] = 0u;
+        if (h < G) qv[r] = reinterpret_cast<const uint32_t*>(a.q + (int64_t)(bh0 + h) * kD + odd * 64)[lane & 31];
+    }
+    h16 mk = (h16)0.f;
+    if constexpr (MASK) mk = (a.mask.ptr + (int64_t)(bh0 / a.mask.heads) * a.mask.stride)[tc * 64 + lane];
+    // ---- trip 2: the four chunks
+    const uint32_t k0 = rl_at<0>(kix), k1 = rl_at<32>(kix), k2 = __builtin_amdgcn_readfirstlane(kie);
+    const Stage sk0 = stage_issue(kn + 4ull * k0, 4u * (k1 - k0), lane);
+    const Stage sk1 = stage_issue(kn + 4ull * k1, 4u * (k2 - k1), lane);
+    const uint32_t v0 = rl_at<0>(vix), v1 = rl_at<32>(vix), v2 = __builtin_amdgcn_readfirstlane(vie);
+    const Stage sv0 = stage_issue(vn + 4ull * v0, 4u * (v1 - v0), lane);
+    const Stage sv1 = stage_issue(vn + 4ull * v1, 4u * (v2 - v1), lane);
+    // Everything above stays above: the phases below are straight-line code in THIS basic block (an idle pair walks the workgroup's first block
+    // and weighs nothing at the merge) -- with a branch around a phase the compiler sinks that phase's loads into it, next to their first use,
+    // and the wave is back to one round trip per phase.
+    __builtin_amdgcn_sched_barrier(0);
+
+    MUSTAFAR_PTRACE_STAMP(1);   // (trace builds: requests issued; the phases' own stamps follow)
+    float sA[G], acc[G];
+#pragma unroll
+    for (int h = 0; h < G; h++) { sA[h] = 0.f; acc[h] = 0.f; }
+    float m_run[HW], l_lane[HW];
+#pragma unroll
+    for (int j = 0; j < HW; j++) { m_run[j] = -INFINITY; l_lane[j] = 0.f; }
+    // ---- key phase: partial scores of the wave's 64 channels, lane = token
+    {
+        small_phase<ENG, G>(lds, lds_addr, lane, sk0, sk1, k0, k1, (uint32_t)kbm, (uint32_t)(kbm >> 32), kix, qv, sA);
+        fvG o;
+        if constexpr (G == 1) o = sA[0];
+        else {
+#pragma unroll
+            for (int h = 0; h < G; h++) o[h] = sA[h];
+        }
+        xch_out[0] = o;
+    }
+    MUSTAFAR_PTRACE_STAMP(2);
+    __syncthreads();
+    // ---- softmax step over the block's 64 tokens: each wave its heads; e -> the pair's table
+    if (has_heads) {
+        const fvH mine = *reinterpret_cast<const fvH*>(xch_mine), part = *reinterpret_cast<const fvH*>(xch_part);
+#pragma unroll
+        for (int j = 0; j < HW; j++) {
+            float p;
+            if constexpr (HW == 1) p = mine + part;
+            else                   p = mine[j] + part[j];
+            float x = scaled((h16)p, a.inv_sqrt_d);   // fp16 score (SpMM_Kernel.cuh:418), / sqrt(d) in fp16 (model :284)
+            if constexpr (MASK) x = masked(x, mk);
+            const float m_new = wave_max_from(x, m_run[j]);
+            const h16 e = (h16)__builtin_amdgcn_exp2f((x - m_new) * 1.44269504f + kEScaleLog2);
+            etab[(h0 + j) * 64 + lane] = e;
+            l_lane[j] += (float)e;
+            m_run[j] = m_new;
+        }
+    }
+    __syncthreads();   // (also: the partner has read my outgoing partial scores; my value phase now rewrites the window)
+    MUSTAFAR_PTRACE_STAMP(3);
+    // ---- value phase: lane = channel of the wave's half
+    {
+        uint32_t ev[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int h = 2 * r + (lane >> 5);
+            ev[r] = reinterpret_cast<const uint32_t*>(etab)[(h < G ? h : 0) * 32 + (lane & 31)];
+        }
+        small_phase<ENG, G>(lds, lds_addr, lane, sv0, sv1, v0, v1, (uint32_t)vbm, (uint32_t)(vbm >> 32), vix, ev, acc);
+    }
+    MUSTAFAR_PTRACE_STAMP(5);
+    // ---- the softmax denominators, then the merge of the two pairs into one slab per head (as decode_onepass_sb_kernel)
+    float l_run[HW];
+#pragma unroll
+    for (int j = 0; j < HW; j++) {
+        l_run[j] = wave_sum(l_lane[j]);
+        if (!act) m_run[j] = -INFINITY;   // an idle pair (a workgroup's second block beyond the cache) weighs nothing
+    }
+    float* red = reinterpret_cast<float*>(smem);                 // [kWaves][G][64]
+    float* s_m = red + kWaves * G * 64;                          // [2 pairs][G]
+    float* s_l = s_m + 2 * G;                                    // [2 pairs][G]
+    __syncthreads();   // every wave is done with its stage window
+    if (has_heads && lane < HW) s_m[pair * G + h0 + lane] = lane ? m_run[HW - 1] : m_run[0];
+    __syncthreads();
+    const int hl = lane & (G - 1);
+    const float mw = s_m[pair * G + hl];
+    const float M = fmaxf(s_m[hl], s_m[G + hl]);
+    const float scale_l = (mw == -INFINITY) ? 0.f : __expf(mw - M) * (ENG == 2 ? 0x1p-15f : 1.f);
+    if (has_heads && lane >= h0 && lane < h0 + HW) s_l[pair * G + lane] = (lane == h0 ? l_run[0] : l_run[HW - 1]) * scale_l;
+#pragma unroll
+    for (int h = 0; h < G; h++)
+        red[(wave * G + h) * 64 + lane] = acc[h] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scale_l), h));
+    __syncthreads();
+    float* slab_o = a.ws_o + ((int64_t)blockIdx.x * a.BH + bh0) * kD;
+    for (int o = threadIdx.x; o < 2 * G * 64; o += kThreads) {
+        const int hh = o >> 6, l = o & 63;
+        const int half = hh / G, h = hh % G;
+        slab_o[h * kD + half * 64 + l] = red[(half * G + h) * 64 + l] + red[((half + 2) * G + h) * 64 + l];
+    }
+    if (threadIdx.x < G) {
+        const int h = threadIdx.x;
+        float* slab_ml = a.ws_ml + ((int64_t)blockIdx.x * a.BH + bh0 + h) * 2;
+        slab_ml[0] = fmaxf(s_m[h], s_m[G + h]);
+        slab_ml[1] = s_l[h] + s_l[G + h];
+    }
+    MUSTAFAR_PTRACE_END(7);
+}
+
 // ------------------------------------------------------------------------------------------------ key SpMV, lean pair form (round 4)
 // The reference entry point Key_SplitK_API (kernel/csrc/SpMM_API.cu:86-139 -> Key_Kernel, SpMM_Kernel.cuh:156-419) on the machinery
 // of the one-pass launch's key phase: two waves share a 64-token block (64 channels each, partial scores folded through LDS), every
@@ -3616,6 +3909,13 @@ inline int onepass_target_wgs(bool pair)
 // workgroup (2) instead of the automatic choice (raised when the slabs would not fit).
 int g_finish1 = [] { const char* e = getenv("MUSTAFAR_FINISH1"); return e ? atoi(e) != 0 : 1; }();   // round 5: the one-thread-per-channel row kernel for rows of <= 64 slabs (mustafar_tune(10, v))
 int g_sb = [] { const char* e = getenv("MUSTAFAR_SB"); return e ? atoi(e) != 0 : 1; }();   // round 5: the super-block pair form (mustafar_tune(8, 0): round 4's pair kernel)
+int g_small = [] { const char* e = getenv("MUSTAFAR_SMALL"); return e ? atoi(e) : 1; }();   // round 6: decode_onepass_small_kernel: 1 = for launches of at most g_small_waves waves (default), 2 = for every launch of two
+                                                                                          // blocks per workgroup, 0 = never (mustafar_tune(11, v))
+int g_small_waves = [] {   // one wave per SIMD: 4 x the CU count
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return (cus > 0 ? cus : 256) * 4;
+}();
 int g_late_prio = 1;    // mustafar_tune(9, 0): no raised priority for a small last round of workgroups (experiments)
 int g_pair_slabs = 0;   // pair form, mustafar_tune(4, 1): a slab per pair instead of one per workgroup (kernel 1.1 us shorter at c3, row kernel 1.5 us longer)
 // g_lean_win_last: the pair form's window workgroups sit BEHIND the SpMV rows of the grid (mustafar_tune(3, 0): in front, round 3a).
@@ -4032,6 +4332,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             }
             hipEvent_t e0 = prof ? g_prof.ev[4 * g_prof.n] : nullptr, e1 = prof ? g_prof.ev[4 * g_prof.n + 1] : nullptr;
             auto kz = static_cast<const unsigned char*>(kc.nz), vz = static_cast<const unsigned char*>(vc.nz);
+            bool small_form = false;
 #define MUSTAFAR_LL(KERNEL)                                                                                                           \
     hipExtLaunchKernelGGL(KERNEL, grid, dim3(kThreads), 0, st, e0, e1, 0, kc.bmp, kz, kc.idx, kc.nz_offset,                            \
                           vc.bmp, vz, vc.idx, vc.nz_offset, a, kc.bmp_head_stride, kc.idx_head_stride, (uint32_t)kc.nz_head_stride,    \
@@ -4049,7 +4350,22 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                 // never touches, and a kernel with a private segment is launched with scratch (+1 % measured on the GQA-4 form); the
                 // extents instantiation has none and serves the same launch with every block in the base views)
                 if (!extents && G == 1) a.nb0 = ntb;
-                if (g_sb && per_wg <= 4) {   // round 5: the super-block pair form (same grid, slabs and window workgroups; a pair walks its <= 2 blocks once)
+                if (g_sb && per_wg == 2 && eng != 1 && onepass_lean_tbw() <= 0 && (g_small == 2 || (g_small == 1 && (int64_t)S1 * gy * kWaves <= g_small_waves))) {
+                    // round 6: the form without a memory wait inside the phases, for launches that do not even put one wave on every SIMD (c1;
+                    // Llama-3-8B 4k x batch 1): there its shorter chain wins 10 %; from two waves per SIMD on (8k x batch 1, c2) its extra
+                    // v_readlane per step cost more than the waits they replace (profiles/r06_probes.txt item 3).  mustafar_tune(11, 2): always
+#define MUSTAFAR_SM(EXTV, MASKV)                                                                              \
+    do {                                                                                                      \
+        if (G == 2)        MUSTAFAR_LL((decode_onepass_small_kernel<0, EXTV, 2, MASKV>));                      \
+        else if (G == 1)   MUSTAFAR_LL((decode_onepass_small_kernel<0, EXTV, 1, MASKV>));                      \
+        else if (eng == 2) MUSTAFAR_LL((decode_onepass_small_kernel<2, EXTV, 4, MASKV>));                      \
+        else               MUSTAFAR_LL((decode_onepass_small_kernel<0, EXTV, 4, MASKV>));                      \
+    } while (0)
+                    if (extents) { if (mask.ptr) MUSTAFAR_SM(true, true); else MUSTAFAR_SM(true, false); }
+                    else         { if (mask.ptr) MUSTAFAR_SM(false, true); else MUSTAFAR_SM(false, false); }
+#undef MUSTAFAR_SM
+                    small_form = true;
+                } else if (g_sb && per_wg <= 4) {   // round 5: the super-block pair form (same grid, slabs and window workgroups; a pair walks its <= 2 blocks once)
 #define MUSTAFAR_SB(EXTV, MASKV)                                                                            \
     do {                                                                                                    \
         if (G == 2)        MUSTAFAR_LL((decode_onepass_sb_kernel<0, EXTV, 2, MASKV>));                       \
@@ -4083,7 +4399,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                 hipExtLaunchKernelGGL(onepass_finish_kernel<>, dim3(Batch_Size), dim3(256), 0, st, prof ? g_prof.ev[4 * g_prof.n + 2] : nullptr,
                                       prof ? g_prof.ev[4 * g_prof.n + 3] : nullptr, 0, ws_o, ws_ml, NS + nchunks, static_cast<h16*>(out), Batch_Size);
             if (prof) { g_prof.onepass++; g_prof.finish++; g_prof.n++; }
-            t_last_choice = eng | (1 << 4) | ((lp ? (g_sb && per_wg <= 4 ? 3 : 2) : 1) << 8);
+            t_last_choice = eng | (1 << 4) | ((lp ? (small_form ? 4 : g_sb && per_wg <= 4 ? 3 : 2) : 1) << 8);
             return (int)hipGetLastError();
         }
         const bool pair = fma_engine() != 1 || G != 4;                      // two waves per block unless the matrix-pipe engine runs
@@ -4357,6 +4673,7 @@ int mustafar_tune(int knob, int value)
         case 8: g_sb = value ? 1 : 0; return 0;
         case 9: g_late_prio = value ? 1 : 0; return 0;
         case 10: g_finish1 = value ? 1 : 0; return 0;
+        case 11: g_small = value < 0 ? 0 : value > 2 ? 2 : value; return 0;   // (round 6: 0 = never the small-launch kernel, 1 = below one wave per SIMD, 2 = for every launch of two blocks per workgroup)
         default: return MUSTAFAR_EINVAL;
     }
 }

@@ -173,3 +173,86 @@ def test_replays_with_alternating_queries_on_one_scratch(hq, hkv, L0, bsz):
         g.replay()
         torch.testing.assert_close(out.float(), _dense(qs[step & 1], Kp, Vp, 0, 0.7, hq // hkv), rtol=4e-3, atol=2e-3,
                                    msg=lambda m, step=step: f"replay {step}: {m}")
+
+
+def _left_pad_mask(bsz, kv_len, pads):
+    m = torch.zeros((bsz, 1, 1, kv_len), dtype=torch.float16, device=DEV)
+    for b, p in enumerate(pads):
+        m[b, :, :, :p] = torch.finfo(torch.float16).min
+    return m
+
+
+@pytest.mark.parametrize("hq,hkv,eng", [(8, 2, "dot2"), (8, 2, "valu"), (8, 4, None), (8, 8, None), (32, 8, "dot2")])
+def test_small_launch_kernel_against_the_super_block_kernel_and_dense(hq, hkv, eng):
+    """Round 6, decode_onepass_small_kernel (spmv.hip): launches of two blocks per workgroup that do not put a wave on every SIMD.  Forced on
+    (mustafar_tune(11, 2)) and off (11, 0: the super-block kernel) on the same cache: both inside the fp16 band around dense attention over
+    oracle-pruned K / V, and within 2 ulp of the output scale of each other -- eager with and without a left-padding mask, through a 256-token
+    trigger (the cache then holds an extent: the EXT instantiation) and as a captured graph replayed with two alternating queries (the e
+    values cross the pair through LDS here; the window length grows under the replays)."""
+    from mustafar_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(23)
+    bsz, D, L0 = 2, 128, 1024 + 32 + 250                 # 1024 compressed tokens, a window six tokens short of the trigger
+    C = 1024
+    groups = hq // hkv
+    K_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    V_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    Kp, Vp = K_all.clone(), V_all.clone()
+    Kp[:, :, :C] = torch.from_numpy(orc.prune_magnitude(K_all[:, :, :C].cpu().numpy(), 0.7)).to(DEV)
+    Vp[:, :, :C] = torch.from_numpy(orc.prune_magnitude(V_all[:, :, :C].cpu().numpy(), 0.7)).to(DEV)
+    kw = {"structure": "one_pass"}
+    if eng:
+        kw["engine"] = eng
+    outs = {}
+    try:
+        for form in (2, 0):
+            assert lib.mustafar_tune(11, form) == 0
+            a = _attn(hq, hkv, **kw)
+            past = a.to_fused(a.build_cache(K_all.clone(), V_all.clone()))
+            K, V = Kp.clone(), Vp.clone()
+            torch.manual_seed(29)
+            got = []
+            for step in range(12):                       # the trigger fires at step 6: steps 7.. read the appended extent
+                q, kn, vn = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+                K, V = torch.cat([K, kn], 2), torch.cat([V, vn], 2)
+                mask = _left_pad_mask(bsz, K.shape[2], (0, 70)) if step % 3 == 2 else None
+                out, past = a.decode(q, kn, vn, past, attention_mask=mask)
+                assert (lib.mustafar_last_decode_choice() >> 8) & 15 == (4 if form else 3), "the launch form asked for did not run"
+                if mask is not None:                     # batch 1: its first 70 columns carry no weight
+                    want = torch.stack([_dense(q[b:b + 1], K[b:b + 1, :, p:], V[b:b + 1, :, p:], 0, 0.7, groups)[0] for b, p in enumerate((0, 70))])
+                else:
+                    want = _dense(q, K, V, 0, 0.7, groups)
+                torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3, msg=lambda m, step=step, form=form: f"form {form} step {step}: {m}")
+                got.append(out.float())
+                if past[4] > C:                          # behind this step the hook pruned + compressed 256 more tokens (model :324): so does the dense reference
+                    K[:, :, C:C + 256] = torch.from_numpy(orc.prune_magnitude(K[:, :, C:C + 256].cpu().numpy(), 0.7)).to(DEV)
+                    V[:, :, C:C + 256] = torch.from_numpy(orc.prune_magnitude(V[:, :, C:C + 256].cpu().numpy(), 0.7)).to(DEV)
+                    C += 256
+            outs[form] = got
+            C = 1024
+        for x, y in zip(outs[2], outs[0]):
+            scale = float(y.abs().max())
+            assert float((x - y).abs().max()) <= 2 * 2.0 ** -11 * scale + 1e-4
+        # ---- captured + replayed with alternating queries
+        assert lib.mustafar_tune(11, 2) == 0
+        a = _attn(hq, hkv, **kw)
+        past = a.to_fused(a.build_cache(K_all[:, :, :1024 + 32].clone(), V_all[:, :, :1024 + 32].clone()))
+        K, V = Kp[:, :, :1024 + 32].clone(), Vp[:, :, :1024 + 32].clone()
+        qs = [torch.randn(bsz, hq, 1, D, device=DEV).half(), (torch.randn(bsz, hq, 1, D, device=DEV) * 1.5).half()]
+        q, kn, vn = (torch.zeros(bsz, h, 1, D, device=DEV, dtype=torch.float16) for h in (hq, hkv, hkv))
+        counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+        a.decode_fused(q, kn, vn, (past[0], past[1].clone(), past[2], past[3].clone(), past[4], past[5]))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out, _ = a.decode_fused(q, kn, vn, past, step_counter=counter)
+            _lib.check(lib.mustafar_counter_add(torch.cuda.current_stream().cuda_stream, counter.data_ptr(), 1), "counter")
+        for step in range(10):
+            k1, v1 = (torch.randn(bsz, hkv, 1, D, device=DEV).half() for _ in range(2))
+            q.copy_(qs[step & 1]); kn.copy_(k1); vn.copy_(v1)
+            K, V = torch.cat([K, k1], 2), torch.cat([V, v1], 2)
+            g.replay()
+            torch.testing.assert_close(out.float(), _dense(qs[step & 1], K, V, 0, 0.7, groups), rtol=4e-3, atol=2e-3,
+                                       msg=lambda m, step=step: f"replay {step}: {m}")
+    finally:
+        lib.mustafar_tune(11, 1)

@@ -272,7 +272,7 @@ def check(asm_text):
     return hazards, loads, waits, exec_stretches, sinks
 
 
-_SCRATCH_FREE = (r"decode_onepass_sb_kernel", r"onepass_finish_kernel", r"key_lean_kernelILi\dELi\dELi\dELb0E", r"value_lean_kernelILi\dELi\dELb0E",
+_SCRATCH_FREE = (r"decode_onepass_sb_kernel", r"decode_onepass_small_kernel", r"onepass_finish_kernel", r"key_lean_kernelILi\dELi\dELi\dELb0E", r"value_lean_kernelILi\dELi\dELb0E",
                  r"value_spmv_kernelILi\dELb[01]ELi\dELi\dELb0E", r"value_combine_kernel")
 
 

@@ -4,7 +4,8 @@
     python tools/quick.py --cfg c3 c5 --set valu dot2 mfma valu:lean=0 valu:onepass=0 dot2:tbw=2
 
 A setting is engine[:key=value...] with engine in valu | dot2 | mfma and keys onepass (0 | 1 | 2), lean (0 | 1), tbw, wgs,
-winlast, pslab, sb (1: round 5's super-block pair kernel, 0: round 4's pair kernel).
+winlast, pslab, sb (1: round 5's super-block pair kernel, 0: round 4's pair kernel), small (1: round 6's kernel for launches of two blocks
+per workgroup, 0: the super-block kernel there too).
 Per setting: self-check against the two reference entry points, then the step replayed as a graph (tokens/s) and the
 kernels' own durations.  One line per (config, setting)."""
 import argparse
@@ -50,6 +51,7 @@ def main():
             _lib.check(lib.mustafar_tune(8, int(kv.get("sb", 1))), "sb")
             _lib.check(lib.mustafar_tune(9, int(kv.get("late", 1))), "late")
             _lib.check(lib.mustafar_tune(10, int(kv.get("fin1", 1))), "fin1")
+            _lib.check(lib.mustafar_tune(11, int(kv.get("small", 1))), "small")
             ex = w.self_check()
             dt, (ku, vu, n) = w.timed_graph(a.steps, 3)
             rl = w.roofline(ku, vu, n, traffic_file=False)
