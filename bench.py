@@ -540,7 +540,7 @@ class Workload:
             dom_bytes = self.alg_val if val_us >= key_us else self.alg_key
             oth_bytes = self.alg_key if val_us >= key_us else self.alg_val
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        traffic, measured_at = None, None
+        traffic, measured_at, items = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch (tools/prof_traffic.sh)
         if traffic_file and os.path.exists(tpath):
             try:
@@ -548,10 +548,14 @@ class Workload:
                 measured_at = tj.get("kernel_source_tag")
                 if measured_at == kernel_source_tag():               # only a figure measured on THESE kernels is reported
                     traffic = tj.get(self.name, {}).get("onepass" if onepass else dom.split("_")[0])
+                    items = tj.get(self.name, {}).get("onepass_items") if onepass else None
             except Exception:
                 traffic = None
         out = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+               "traffic_note": "PMC bytes per launch, every read priced as a wide read (2 x FETCH_SIZE + WRITE_SIZE): an upper bound -- the 64-byte metadata requests "
+                               "are doubled with the rest; traffic_itemised (c3: profiles/r06_traffic_items.txt) prices only the packed streams as wide",
+               "traffic_itemised": items,
                "traffic_measured_at": measured_at, "kernel_source_tag": kernel_source_tag(),
                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 2), "launches_timed": n,
                "timing_source": "kernel start/stop timestamps (hipExtLaunchKernel events) of an EAGER pass over the same state "
@@ -624,6 +628,7 @@ def run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib):
     dt, (ku, vu, n) = w.timed_graph(steps, 2)
     rl = w.roofline(ku, vu, n)
     out = {"workload": w.label, "value": round(world * w.batch * steps / dt, 2), "unit": "tokens/s", "ms_per_step": round(dt / steps * 1e3, 4),
+           "infinity_cache_sized": bool((w.alg_key + w.alg_val) < 256e6 / 4),   # (a layer's bytes against a quarter of the 256 MiB Infinity Cache: cache-resident rather than HBM-bound -- BASELINE.md section 2)
            "steps": steps, "self_check_excess": round(excess, 3),
            "kernel": rl["kernel"], "kernel_us": rl["avg_launch_us"], "roofline_frac": rl["frac"], "roofline_achieved_GBps": rl["achieved"],
            "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"], "traffic": rl["traffic"], "kv_bytes_reference_layout": int(w.ref_kv_bytes), "dense_kv_bytes": int(w.dense_bytes),
@@ -844,7 +849,7 @@ def main():
     if world == 1 and not a.no_other_configs and a.api == "fused" and not a.no_graph:
         del w
         torch.cuda.empty_cache()
-        for name in ("c2", "c4", "c5", "b1"):   # (b1: the headline's geometry and length at batch 1 -- what single-user decode looks like; not a BASELINE config)
+        for name in ("c2", "c4", "c5", "b1"):   # (c2's whole layer is under 64 MB: Infinity-Cache-sized, flagged in its entry; b1: the headline's geometry and length at batch 1 -- what single-user decode looks like; not a BASELINE config)
             if name != a.config:
                 sub[name] = run_sub_config(name, a, dev, rank, world, dist, rehearse, timer, lib)
 

@@ -18,7 +18,7 @@ for tag, cname in (("F", "FETCH_SIZE"), ("W", "WRITE_SIZE")):
     acc = {}
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        for name in ("key_spmv_kernel", "key_lean_kernel", "value_spmv_kernel", "value_lean_kernel", "decode_onepass_sb", "decode_onepass_leanpair", "decode_onepass_kernel"):
+        for name in ("key_spmv_kernel", "key_lean_kernel", "value_spmv_kernel", "value_lean_kernel", "decode_onepass_sb", "decode_onepass_small", "decode_onepass_leanpair", "decode_onepass_kernel"):
             if name in k and r["Counter_Name"] == cname:
                 acc.setdefault(name, []).append(float(r["Counter_Value"]) * 1024)
     for name, v in acc.items():

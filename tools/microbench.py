@@ -22,6 +22,7 @@ CFG = {  # name: (Hq, Hkv, sparsity, L, batch)
     "c3": (32, 8, 0.7, 8192, 8),
     "c4": (32, 8, 0.8, 32768, 4),
     "c5": (32, 8, 0.7, 16384, 16),
+    "b1": (32, 8, 0.7, 8192, 1),      # Llama-3-8B 8k x batch 1 (tools only)
 }
 
 
