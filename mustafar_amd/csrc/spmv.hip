@@ -1521,6 +1521,9 @@ struct OneArgs {   // operands of the one-pass launch beyond the two caches (by 
     // workgroups of a launch's LAST, nearly empty round (a cache a trigger or two past one resident round of workgroups: T = 8448 at c3's
     // geometry is 2112 workgroups on 2048 slots) start when the first slots free up and would otherwise crawl along at an eighth of a SIMD
     int hi_prio_from = 0x7fffffff;
+    // round 6 (experiment, mustafar_tune(12, bytes)): expected bytes of key stream per 64-token block; > 0: a wave asks for the lines around
+    // the PREDICTED position of its first key chunk next to its bounds load (see decode_onepass_sb_kernel)
+    int spec_k_bytes = 0;
 };
 
 // Window workgroup: 64 window tokens of one head batch -> scores, softmax partial, p.V partial -> slab (S + chunk).
@@ -3019,6 +3022,10 @@ __device__ __forceinline__ uint32_t ld_at(const void* __restrict__ sbase, uint32
 {
     return *reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(sbase) + voff);
 }
+#ifndef MUSTAFAR_SPEC_LINES
+#define MUSTAFAR_SPEC_LINES 16    // (experiment: 128-byte lines of the speculative first-chunk request, a power of two <= 64; MUSTAFAR_SPEC_BACK bytes in front of the prediction)
+#define MUSTAFAR_SPEC_BACK 512
+#endif
 template <int ENG, bool EXT = false, int G = 4, bool MASK = false>   // (a pair walks ONE super-block: launches of more than four blocks per workgroup run
                                                                      // decode_onepass_leanpair_kernel; round 5 carried an uninstantiated online form here -- removed in round 6)
 __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
@@ -3172,6 +3179,14 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
             const uint32_t* kiA = ki + (int64_t)tAc * kTilesPerTb;
             uint32_t bndK = ld_at(kiA, off_bnd);
             const uint32_t pfKA = ld_at(kbA, off_bmp);
+            uint32_t pfS = 0;
+            if (a.spec_k_bytes > 0 && k_nz_stride && !(EXT && tb0 >= a.nb0)) {
+                // speculative request for the first key chunk (behind the bounds load in program order: the bounds' wait does not cover it): 32 lines of
+                // 128 bytes from 1 KiB in front of where block tAc's half would start if every block had the average length, clamped to the head's region
+                const int64_t pred = (int64_t)tAc * a.spec_k_bytes + (odd ? a.spec_k_bytes / 2 : 0) - MUSTAFAR_SPEC_BACK + (lane & (MUSTAFAR_SPEC_LINES - 1)) * 128;
+                const int64_t last = (int64_t)k_nz_stride * 16 - 4;
+                pfS = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(kn + ((uint32_t)(pred < 0 ? 0 : pred > last ? last : pred) & ~3u)));
+            }
             if constexpr (MASK) {
                 mkA = mrow[tAc * 64 + lane];
                 if (actB) mkB = mrow[tBc * 64 + lane];
@@ -3190,9 +3205,11 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
                 lean_pair_phase<ENG, kD * 2, false, G>(lds, lds_addr, kbA, kiA, kn, qb, bndK, lane, sA, sB MUSTAFAR_PTRACE_ARG, ctab_q, reqKB, reqVA);
                 prefetch_done(pfKA);
                 prefetch_done(pfKB);
+                prefetch_done(pfS);
             } else {
                 lean_block_phase<ENG, kD * 2, false, 0, 2, G, const void*, 0>(lds, lds_addr, kbA, kiA, kn, qb, bndK, lane, sA, sA MUSTAFAR_PTRACE_ARG, ctab_q, reqVA);
                 prefetch_done(pfKA);
+                prefetch_done(pfS);
             }
             fvG oA, oB;
             if constexpr (G == 1) { oA = sA[0]; oB = sB[0]; }
@@ -3916,6 +3933,7 @@ int g_small_waves = [] {   // one wave per SIMD: 4 x the CU count
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return (cus > 0 ? cus : 256) * 4;
 }();
+int g_spec_k_bytes = 0; // mustafar_tune(12, bytes): experiment, see OneArgs::spec_k_bytes
 int g_late_prio = 1;    // mustafar_tune(9, 0): no raised priority for a small last round of workgroups (experiments)
 int g_pair_slabs = 0;   // pair form, mustafar_tune(4, 1): a slab per pair instead of one per workgroup (kernel 1.1 us shorter at c3, row kernel 1.5 us longer)
 // g_lean_win_last: the pair form's window workgroups sit BEHIND the SpMV rows of the grid (mustafar_tune(3, 0): in front, round 3a).
@@ -4314,6 +4332,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
             if (extents && (!lp || (per_wg != 2 && per_wg != 4))) return MUSTAFAR_EINVAL;   // a workgroup's blocks stay inside one extent
             OneArgs a{qh, sc, ws_o, ws_ml, kwin, vwin, knew, vnew, window_len_extra, mask, T, groups, Batch_Size, lp ? per_wg : per_wg / kWaves,
                       ld_scores, window_len, window_capacity, nchunks, g_lean_win_last ? -win_rows : win_rows, inv_sqrt_d0, spw == 2};
+            a.spec_k_bytes = g_spec_k_bytes;
             if (extents) {
                 a.k_ext = k_ext;
                 a.v_ext = v_ext;
@@ -4673,6 +4692,7 @@ int mustafar_tune(int knob, int value)
         case 8: g_sb = value ? 1 : 0; return 0;
         case 9: g_late_prio = value ? 1 : 0; return 0;
         case 10: g_finish1 = value ? 1 : 0; return 0;
+        case 12: g_spec_k_bytes = value < 0 ? 0 : value; return 0;
         case 11: g_small = value < 0 ? 0 : value > 2 ? 2 : value; return 0;   // (round 6: 0 = never the small-launch kernel, 1 = below one wave per SIMD, 2 = for every launch of two blocks per workgroup)
         default: return MUSTAFAR_EINVAL;
     }

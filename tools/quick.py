@@ -52,6 +52,11 @@ def main():
             _lib.check(lib.mustafar_tune(9, int(kv.get("late", 1))), "late")
             _lib.check(lib.mustafar_tune(10, int(kv.get("fin1", 1))), "fin1")
             _lib.check(lib.mustafar_tune(11, int(kv.get("small", 1))), "small")
+            spec = 0
+            if kv.get("spec"):   # (round 6 experiment) spec=1: the measured average bytes of key stream per block; spec=<n>: n bytes
+                st0 = w.fused_state()[0]
+                spec = int(kv["spec"]) if int(kv["spec"]) > 1 else int(2 * float(st0[0].used.double().mean()) / (st0[4] // 64))
+            _lib.check(lib.mustafar_tune(12, spec), "spec")
             ex = w.self_check()
             dt, (ku, vu, n) = w.timed_graph(a.steps, 3)
             rl = w.roofline(ku, vu, n, traffic_file=False)
