@@ -1042,6 +1042,9 @@ __device__ __forceinline__ void value_tokblks(unsigned char* smem, uint32_t lds_
 #else
 #define MUSTAFAR_VALUE_BOUNDS __launch_bounds__(NW * 64, MF ? MUSTAFAR_VALUE_MF_WAVES : 1)
 #endif
+#ifndef MUSTAFAR_PAD_LATE
+#define MUSTAFAR_PAD_LATE 0   // (0 = the pad rows are read and reduced in front of row 0, rounds 1-5; 1 = requested in front, looked at behind row 0; 2 = read and looked at behind row 0)
+#endif
 template <int G, bool MF, int NW, int SPLIT, bool WIN = true>   // WIN = false: no window workgroups in the launch (the reference entry point): round 5, as key_lean_kernel
 __global__ MUSTAFAR_VALUE_BOUNDS void value_spmv_kernel(
     const uint64_t* __restrict__ bmp, const unsigned char* __restrict__ nz, const uint32_t* __restrict__ idx,
@@ -1085,13 +1088,49 @@ __global__ MUSTAFAR_VALUE_BOUNDS void value_spmv_kernel(
     const uint32_t chead = (uint32_t)N * ((uint32_t)ldb / 2u);
 
     uint32_t rows = 1u;
-    if (N > 1) {
-        rows |= pad_row_mask<G>(p, ldb, bh0, N, tb0 * 64, (tb_end - tb0) * 64,
-                                reinterpret_cast<uint32_t*>(smem));
+    // Pad rows (N > 1; the hook's seven zero rows, llama_mustafar_kernel.py:313): they must be READ to be known zero -- 28 MB per call at c3 -- but
+    // nobody has to wait for them.  Round 6: the workgroup's slice of them is requested here, row 0 is computed, and only then is the slice
+    // looked at (rounds 1-5 read, reduced and synchronised in front of row 0: two barriers and an exposed round trip per workgroup).
+    constexpr int kPadRegs = 4;   // 16-byte pieces per thread kept in flight: G x 7 rows x 256 tokens over 256 threads = 3.5
+    uint4 padv[kPadRegs];
+    const int pad_cols = (tb_end - tb0) * 64, pad_per_row = pad_cols / 8;
+    const int npad = N > 1 ? G * (N - 1) * pad_per_row : 0;
+    const bool pad_regs = N > 1 && npad <= kPadRegs * NW * 64 && MUSTAFAR_PAD_LATE == 1;
+    if (pad_regs) {
+#pragma unroll
+        for (int i = 0; i < kPadRegs; i++) {
+            const int u = min((int)threadIdx.x + i * NW * 64, npad - 1);   // (no divergent branch in front of the rows' asm statements: a lane beyond the slice repeats its last piece)
+            const int hn = u / pad_per_row, k = u % pad_per_row;
+            const int h = hn / (N - 1), n = 1 + hn % (N - 1);
+            padv[i] = *reinterpret_cast<const uint4*>(p + ((int64_t)(bh0 + h) * N + n) * ldb + tb0 * 64 + k * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (the requests stay in front of row 0: without it the compiler sinks them to their use behind it)
+    } else if (N > 1 && MUSTAFAR_PAD_LATE != 2) {
+        rows |= pad_row_mask<G>(p, ldb, bh0, N, tb0 * 64, pad_cols, reinterpret_cast<uint32_t*>(smem));
         if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + by] = rows;   // (no window rows when N > 1)
     }
 
     for (int n = 0; n < N; n++) {
+        if (n == 1 && MUSTAFAR_PAD_LATE == 2) {   // (2: the slice is read AND looked at behind row 0 -- nothing in front of the workgroup's first stream request)
+            rows |= pad_row_mask<G>(p, ldb, bh0, N, tb0 * 64, pad_cols, reinterpret_cast<uint32_t*>(smem));
+            if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + by] = rows;
+        }
+        if (n == 1 && pad_regs) {   // (workgroup-uniform) row 0 is done: which pad rows hold a non-zero in this workgroup's columns?
+            uint32_t* sh_mask = reinterpret_cast<uint32_t*>(smem);   // (behind the barrier that ended row 0: the stage windows are free)
+            if (threadIdx.x == 0) *sh_mask = 0u;
+            __syncthreads();
+            uint32_t mine = 0;
+#pragma unroll
+            for (int i = 0; i < kPadRegs; i++) {
+                const int u = threadIdx.x + i * NW * 64;
+                if (u < npad && nzbits(padv[i])) mine |= 1u << (1 + (u / pad_per_row) % (N - 1));
+            }
+            if (mine) atomicOr(sh_mask, mine);
+            __syncthreads();
+            rows |= (uint32_t)__builtin_amdgcn_readfirstlane((int)*sh_mask);   // (wave-uniform, and known to the compiler as such: the rows' asm statements own EXEC)
+            __syncthreads();
+            if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + by] = rows;
+        }
         const bool live = (rows >> n) & 1u;
         if (!live && !direct) continue;   // the combine pass skips this row of this slab
         float acc0[G], acc1[G];

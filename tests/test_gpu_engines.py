@@ -58,8 +58,9 @@ def test_two_instances_each_run_their_own_structure_and_engine():
     q, kn, vn = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
     want = _dense(q, torch.cat([K, kn], 2), torch.cat([V, vn], 2), 1024, 0.7, hq // hkv)
     # (engine that must run, structure, one-pass form) by instance; mustafar_last_decode_choice() reports what the call launched
-    cases = (("dot2", "one_pass", 2 | 1 << 4 | 3 << 8), ("valu", "one_pass", 0 | 1 << 4 | 3 << 8), ("mfma", "one_pass", 1 | 1 << 4 | 3 << 8),
-             ("valu", "two_launch", 0), ("mfma", "two_launch", 1), (None, None, 2 | 1 << 4 | 3 << 8))
+    # (one-pass form 4 = round 6's small-launch kernel: this shape is 16 workgroups; the matrix-pipe engine keeps the super-block kernel, form 3)
+    cases = (("dot2", "one_pass", 2 | 1 << 4 | 4 << 8), ("valu", "one_pass", 0 | 1 << 4 | 4 << 8), ("mfma", "one_pass", 1 | 1 << 4 | 3 << 8),
+             ("valu", "two_launch", 0), ("mfma", "two_launch", 1), (None, None, 2 | 1 << 4 | 4 << 8))
     attns = [(_attn(hq, hkv, engine=e, structure=st), code) for e, st, code in cases]
     pasts = [a.to_fused(a.build_cache(K.clone(), V.clone())) for a, _ in attns]
     for rnd in range(2):                              # interleaved: no instance inherits what the previous call chose

@@ -195,7 +195,7 @@ def check(asm_text):
                 pend = _smem_step(code, pend, lambda c, ln=ln: hazards.append((kernel, ln, c)))
         # ---- (2) EXEC discipline, (3) sink register: text order
         in_asm = exec_masked = False
-        divergent = 0
+        divergent, saved = 0, []
         sink_regs, sink_lines, vwrites, sink_end = set(), set(), [], None
         for ln, code, _ in ins:
             if code == "#SINKEND":
@@ -228,10 +228,20 @@ def check(asm_text):
                     sink_regs |= vgprs(args[0])
                     sink_lines.add(ln)
                     sinks += 1
-            elif "saveexec" in op:
-                divergent += 1
-            elif op == "s_or_b64" and args[:2] == ["exec", "exec"] and divergent:
-                divergent -= 1
+            elif "saveexec" in op and args:
+                saved.append(args[0])          # (the register pair that holds the mask to come back to)
+                divergent = len(saved)
+            elif op == "s_andn2_b64" and args[:2] == ["exec", "exec"] and len(args) > 2 and args[2] not in saved:
+                saved.append(args[2])          # (a divergent loop sheds lanes; `s_or_b64 exec, exec, <the same pair>` brings them back)
+                divergent = len(saved)
+            elif op == "s_or_b64" and args[:2] == ["exec", "exec"] and saved:
+                # restoring a mask closes its region AND every region opened inside it (round 6: an inner `if` at the very end of an outer one is
+                # closed by the outer restore alone -- counting restores against saves left the depth at 1 for the rest of the kernel)
+                if len(args) > 2 and args[2] in saved:
+                    del saved[saved.index(args[2]):]
+                else:
+                    saved.pop()
+                divergent = len(saved)
             # destination registers of vector instructions / loads (first operand; stores and compares write no VGPR)
             if args and (op.startswith("v_") or op.startswith("ds_read") or op.startswith("buffer_load") or op.startswith("global_load") or
                          op.startswith("flat_load") or op.startswith("scratch_load")) and not op.startswith("v_cmp") and not op.startswith("v_writelane_b32_dummy"):
