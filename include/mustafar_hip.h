@@ -340,7 +340,10 @@ int mustafar_get_onepass(void);
  * | structure << 4 (0 two launches, 1 one-pass) | one-pass form << 8 (0 round-2 forms, 1 lean whole-block, 2 lean pair grain, 3 super-block pair form: round 5, the default from 768 workgroups on, 4 the small-launch form: round 6, the default below that);
  * -1 before the first call.  For tests and tools: a call's `flags` and the process defaults can be checked against what ran. */
 int mustafar_last_decode_choice(void);
-/* Tuning knobs for the measurement scripts under tools/ (launch shapes of the one-pass forms); not an operator interface. */
+/* Tuning knobs for the measurement scripts under tools/ (launch shapes of the one-pass forms); not an operator interface.
+ * Round 6: knob 11 = the small-launch kernel (0 never, 1 launches of two blocks per workgroup that put at most one wave on every SIMD -- the
+ * default, 2 every launch of two blocks per workgroup); knob 12 = bytes of key stream per block for the speculative first-chunk request
+ * (an experiment that measured slower; 0 = off, the default). */
 int mustafar_tune(int knob, int value);
 
 /*

@@ -1088,9 +1088,11 @@ __global__ MUSTAFAR_VALUE_BOUNDS void value_spmv_kernel(
     const uint32_t chead = (uint32_t)N * ((uint32_t)ldb / 2u);
 
     uint32_t rows = 1u;
-    // Pad rows (N > 1; the hook's seven zero rows, llama_mustafar_kernel.py:313): they must be READ to be known zero -- 28 MB per call at c3 -- but
-    // nobody has to wait for them.  Round 6: the workgroup's slice of them is requested here, row 0 is computed, and only then is the slice
-    // looked at (rounds 1-5 read, reduced and synchronised in front of row 0: two barriers and an exposed round trip per workgroup).
+    // Pad rows (N > 1; the hook's seven zero rows, llama_mustafar_kernel.py:313): they must be READ to be known zero -- 28 MB per call at c3.
+    // Round 6 measured WHERE in the workgroup's life they are read (MUSTAFAR_PAD_LATE; c3, N = 8, us per call, same box): in front of row 0
+    // (rounds 1-5, the default) 38.6-40.0; requested in front and looked at behind row 0 (1) 42.6-43.9 -- sixteen more registers, and loads return
+    // in order, so the first stream chunk waits for them all the same; read and looked at behind row 0 (2) 39.7-42.0, c5 109 against 103.  The call
+    // moves 1.43 x the bytes of the N = 1 call and takes 1.49 x its time: it is the bytes, not their place (profiles/r06_probes.txt item 5).
     constexpr int kPadRegs = 4;   // 16-byte pieces per thread kept in flight: G x 7 rows x 256 tokens over 256 threads = 3.5
     uint4 padv[kPadRegs];
     const int pad_cols = (tb_end - tb0) * 64, pad_per_row = pad_cols / 8;
