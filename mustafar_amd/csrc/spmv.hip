@@ -3063,6 +3063,12 @@ __device__ __forceinline__ uint32_t ld_at(const void* __restrict__ sbase, uint32
 {
     return *reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(sbase) + voff);
 }
+#ifndef MUSTAFAR_SB_TRIPLOOP
+#define MUSTAFAR_SB_TRIPLOOP 1
+#endif
+#ifndef MUSTAFAR_SPEC
+#define MUSTAFAR_SPEC 0           // (experiment, measured slower: the speculative first-chunk request of DESIGN 4.1 item 25 is compiled in only with -DMUSTAFAR_SPEC=1)
+#endif
 #ifndef MUSTAFAR_SPEC_LINES
 #define MUSTAFAR_SPEC_LINES 16    // (experiment: 128-byte lines of the speculative first-chunk request, a power of two <= 64; MUSTAFAR_SPEC_BACK bytes in front of the prediction)
 #define MUSTAFAR_SPEC_BACK 512
@@ -3197,6 +3203,13 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
     if (late_round) __builtin_amdgcn_s_setprio(3);
     else if (MUSTAFAR_SB_PRIO) __builtin_amdgcn_s_setprio(1);
     asm volatile("; sb_trips_begin");   // (markers for tools/isa_breakdown.py --markers: a comment in the ISA, no instruction)
+#if MUSTAFAR_SB_TRIPLOOP
+    // ONE trip, written as a loop the compiler may not unroll: a scheduling region boundary around the trip.  It computes the same thing as the bare block;
+    // what it changes is where the register allocator reloads its 30-odd spilled scalars (bare block: 14 more v_readlane, several of them inside the steps of
+    // the phases: ~1 us at c3, profiles/r06_probes.txt item 6).  Correctness does not hang on it (round 6, item 1: the DOT guard does that job).
+#pragma unroll 1
+    for (int trip = 0; trip < 1; trip++)
+#endif
     {
         const int tA = pb0;
         const bool actA = tA < pb_end, actB = tA + 1 < pb_end;   // (wave-uniform)
@@ -3221,7 +3234,7 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
             uint32_t bndK = ld_at(kiA, off_bnd);
             const uint32_t pfKA = ld_at(kbA, off_bmp);
             uint32_t pfS = 0;
-            if (a.spec_k_bytes > 0 && k_nz_stride && !(EXT && tb0 >= a.nb0)) {
+            if (MUSTAFAR_SPEC && a.spec_k_bytes > 0 && k_nz_stride && !(EXT && tb0 >= a.nb0)) {
                 // speculative request for the first key chunk (behind the bounds load in program order: the bounds' wait does not cover it): 32 lines of
                 // 128 bytes from 1 KiB in front of where block tAc's half would start if every block had the average length, clamped to the head's region
                 const int64_t pred = (int64_t)tAc * a.spec_k_bytes + (odd ? a.spec_k_bytes / 2 : 0) - MUSTAFAR_SPEC_BACK + (lane & (MUSTAFAR_SPEC_LINES - 1)) * 128;
@@ -3246,11 +3259,11 @@ __global__ MUSTAFAR_LP_BOUNDS void decode_onepass_sb_kernel(
                 lean_pair_phase<ENG, kD * 2, false, G>(lds, lds_addr, kbA, kiA, kn, qb, bndK, lane, sA, sB MUSTAFAR_PTRACE_ARG, ctab_q, reqKB, reqVA);
                 prefetch_done(pfKA);
                 prefetch_done(pfKB);
-                prefetch_done(pfS);
+                if (MUSTAFAR_SPEC) prefetch_done(pfS);
             } else {
                 lean_block_phase<ENG, kD * 2, false, 0, 2, G, const void*, 0>(lds, lds_addr, kbA, kiA, kn, qb, bndK, lane, sA, sA MUSTAFAR_PTRACE_ARG, ctab_q, reqVA);
                 prefetch_done(pfKA);
-                prefetch_done(pfS);
+                if (MUSTAFAR_SPEC) prefetch_done(pfS);
             }
             fvG oA, oB;
             if constexpr (G == 1) { oA = sA[0]; oB = sB[0]; }

@@ -40,7 +40,10 @@ done
 PROF_FUSED=1 MUSTAFAR_FMA_ENGINE=mfma tools/prof_pmc.sh ${TAG}_mfma_c5 c5 > /dev/null; cp gpurun_out/pmc_${TAG}_mfma_c5.txt $O/pmc_sq_c5_mfma.txt
 echo "pmc done"
 fi
-if [ "$PART" = A ]; then echo "part A done"; ls $O; exit 0; fi
+if [ "$PART" = A ]; then   # (only the summaries travel back: gpurun merges at most 64 MiB)
+  rm -rf $R/gpurun_out/pmc_${TAG}_* $R/gpurun_out/traffic_${TAG}_* $O/rocprof_bench
+  echo "part A done"; ls $O; exit 0
+fi
 
 python3 tools/wave_trace_onepass.py --cfg c3 --set dot2 mfma > $O/wave_trace_c3.txt 2> $O/wave_trace.err; nonempty $O/wave_trace_c3.txt
 python3 tools/wave_trace_onepass.py --cfg c4 --set dot2 mfma > $O/wave_trace_c4.txt 2>> $O/wave_trace.err; nonempty $O/wave_trace_c4.txt
