@@ -257,3 +257,50 @@ def test_small_launch_kernel_against_the_super_block_kernel_and_dense(hq, hkv, e
                                        msg=lambda m, step=step: f"replay {step}: {m}")
     finally:
         lib.mustafar_tune(11, 1)
+
+
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 8)])
+@pytest.mark.parametrize("kind", ["dense", "one_half", "zero_block"])
+def test_one_pass_forms_on_extreme_tiles(hq, hkv, kind):
+    """The fused launch on the tiles SURVEY 8d calls adversarial, for the three one-pass forms that serve ordinary shapes -- the small-launch kernel (round 6),
+    the super-block kernel with two and with four blocks per workgroup: `dense` = nothing pruned (sparsity 0: every tile holds 64 non-zeros, every chunk
+    fills its 4-KiB stage window to the last byte); `one_half` = every kept value of a token in channels 0..63 (value tiles of the upper half and key tiles of channels
+    64..127 are EMPTY, the others carry twice the usual non-zeros); `zero_block` = 64 tokens of exact zeros in the middle of the cache (zero-length chunks)."""
+    from mustafar_amd import _lib
+    from mustafar_amd.hook import MustafarAttention, MustafarConfig
+    lib = _lib.load()
+    torch.manual_seed(31)
+    bsz, D, L0 = 2, 128, 1024 + 40
+    C, groups = 1024, hq // hkv
+    s = 0.0 if kind == "dense" else 0.7
+    K_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    V_all = torch.randn(bsz, hkv, L0, D, device=DEV).half()
+    if kind == "one_half":
+        K_all[..., 64:] *= 1e-3
+        V_all[..., 64:] *= 1e-3
+    if kind == "zero_block":
+        K_all[:, :, 448:512] = 0
+        V_all[:, :, 448:512] = 0
+    Kp, Vp = K_all.clone(), V_all.clone()
+    if s > 0:
+        Kp[:, :, :C] = torch.from_numpy(orc.prune_magnitude(K_all[:, :, :C].cpu().numpy(), s)).to(DEV)
+        Vp[:, :, :C] = torch.from_numpy(orc.prune_magnitude(V_all[:, :, :C].cpu().numpy(), s)).to(DEV)
+    q, kn, vn = (torch.randn(bsz, h, 1, D, device=DEV).half() for h in (hq, hkv, hkv))
+    want = _dense(q, torch.cat([Kp, kn], 2), torch.cat([Vp, vn], 2), 0, 0.7, groups)
+    outs = []
+    try:
+        for small, tbw, form in ((2, 0, 4), (0, 0, 3), (0, 2, 3)):        # small-launch kernel; super-block kernel, two blocks per workgroup; four
+            assert lib.mustafar_tune(11, small) == 0 and lib.mustafar_tune(1, tbw) == 0
+            a = MustafarAttention(MustafarConfig(num_attention_heads=hq, num_key_value_heads=hkv, k_sparsity=s, v_sparsity=s, api="fused", arena=True,
+                                                 structure="one_pass"))
+            past = a.to_fused(a.build_cache(K_all.clone(), V_all.clone()))
+            out, _ = a.decode(q, kn, vn, past)
+            assert (lib.mustafar_last_decode_choice() >> 8) & 15 == form
+            torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=2e-3, msg=lambda m, f=(small, tbw): f"form {f}: {m}")
+            outs.append(out.float())
+        scale = float(want.abs().max())
+        for o in outs[1:]:
+            assert float((o - outs[0]).abs().max()) <= 2 * 2.0 ** -11 * scale + 1e-4
+    finally:
+        lib.mustafar_tune(11, 1)
+        lib.mustafar_tune(1, 0)

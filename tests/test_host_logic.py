@@ -298,3 +298,53 @@ def test_stream_pieces_make_the_hooks_torch_cat_free():
     assert float(merged[0][0]) == 0.0 and float(merged[0][1]) == 1.0 and float(again[1]) == 1.0
     # ordinary tensor behaviour of a piece
     assert float(ps[0][-1]) == 7.0 and type(ps[2] * 2) is torch.Tensor and ps[3].view(2, 8).shape == (2, 8) and len(ps[2]) == 16
+
+
+def _checker():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_smem_hazards", os.path.join(ROOT, "tools", "check_smem_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_FAKE_KERNEL = """\t.text
+_Zfake_kernel:
+\ts_load_dwordx4 s[4:7], s[0:1], 0x0
+\ts_waitcnt lgkmcnt(0)
+%s
+\ts_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_checker_flags_a_dot_result_without_its_wait_states():
+    """tools/check_smem_hazards.py check (6), on hand-written ISA: a v_dot2 at the end of an asm statement (the round-6 bug: the compiler put a
+    move of the accumulator one wait state behind it), the same with `s_nop 3` behind it, and a different vector instruction inside the
+    statement that reads / overwrites the result too early."""
+    mod = _checker()
+    dots = lambda body: mod.check_dot_hazards(_FAKE_KERNEL % body)
+    bad, n = dots("\t;;#ASMSTART\n\tv_dot2_f32_f16 v9, v23, s4, v9\n\t;;#ASMEND\n\tv_mov_b32_e32 v29, v9")
+    assert n == 1 and len(bad) == 1 and "wait state" in bad[0][2]
+    bad, n = dots("\t;;#ASMSTART\n\tv_dot2_f32_f16 v9, v23, s4, v9\n\ts_nop 3\n\t;;#ASMEND\n\tv_mov_b32_e32 v29, v9")
+    assert n == 1 and not bad
+    # back-to-back accumulation by the same opcode is fine; four independent dots behind the last one are its wait states
+    bad, n = dots("\t;;#ASMSTART\n\tv_dot2_f32_f16 v9, v23, s4, v9\n\tv_dot2_f32_f16 v9, v24, s5, v9\n\tv_dot2_f32_f16 v6, v23, s4, v6\n"
+                  "\tv_dot2_f32_f16 v7, v23, s4, v7\n\tv_dot2_f32_f16 v8, v23, s4, v8\n\tv_dot2_f32_f16 v5, v23, s4, v5\n\ts_nop 3\n\t;;#ASMEND")
+    assert n == 6 and not bad
+    bad, _ = dots("\t;;#ASMSTART\n\tv_dot2_f32_f16 v9, v23, s4, v9\n\tv_add_f32_e32 v1, v9, v9\n\ts_nop 3\n\t;;#ASMEND")      # read 0 wait states behind
+    assert len(bad) == 1 and "touches the result" in bad[0][2]
+    bad, _ = dots("\t;;#ASMSTART\n\tv_dot2_f32_f16 v9, v23, s4, v9\n\ts_nop 2\n\tv_mov_b32 v9, 0\n\ts_nop 3\n\t;;#ASMEND")          # overwritten 3 behind: needs 4
+    assert len(bad) == 1
+
+
+def test_checker_tracks_divergent_regions_by_the_saved_mask():
+    """Check (2): an asm statement that loads EXEC with a bitmap may not sit inside a compiler-made divergent region.  An inner `if` at the very end of an
+    outer one is closed by the OUTER restore alone (round 6: counting restores against saves left the depth at 1 for the rest of the kernel)."""
+    mod = _checker()
+    asm = "\t;;#ASMSTART\n\ts_mov_b64 exec, s[20:21]\n\tv_mov_b32 v1, 0\n\ts_mov_b64 exec, -1\n\t;;#ASMEND"
+    run = lambda body: [h for h in mod.check(_FAKE_KERNEL % body)[0] if "divergent" in h[2]]
+    nested = "\ts_and_saveexec_b64 s[8:9], vcc\n\ts_and_saveexec_b64 s[10:11], vcc\n\ts_xor_b64 s[10:11], exec, s[10:11]\n\tv_mov_b32_e32 v2, 0\n\ts_or_b64 exec, exec, s[8:9]\n"
+    assert not run(nested + asm), "both regions are closed by the outer restore"
+    assert len(run("\ts_and_saveexec_b64 s[8:9], vcc\n" + asm + "\n\ts_or_b64 exec, exec, s[8:9]")) == 1, "an asm statement inside an open region is reported"
+    assert not run("\ts_and_saveexec_b64 s[8:9], vcc\n\tv_mov_b32_e32 v2, 0\n\ts_or_b64 exec, exec, s[8:9]\n" + asm)
