@@ -3980,13 +3980,17 @@ inline int onepass_target_wgs(bool pair)
 // workgroup (2) instead of the automatic choice (raised when the slabs would not fit).
 int g_finish1 = [] { const char* e = getenv("MUSTAFAR_FINISH1"); return e ? atoi(e) != 0 : 1; }();   // round 5: the one-thread-per-channel row kernel for rows of <= 64 slabs (mustafar_tune(10, v))
 int g_sb = [] { const char* e = getenv("MUSTAFAR_SB"); return e ? atoi(e) != 0 : 1; }();   // round 5: the super-block pair form (mustafar_tune(8, 0): round 4's pair kernel)
-int g_small = [] { const char* e = getenv("MUSTAFAR_SMALL"); return e ? atoi(e) : 1; }();   // round 6: decode_onepass_small_kernel: 1 = for launches of at most g_small_waves waves (default), 2 = for every launch of two
+int g_small = [] { const char* e = getenv("MUSTAFAR_SMALL"); return e ? atoi(e) : 1; }();   // round 6: decode_onepass_small_kernel: 1 = for launches of at most small_waves() waves (default), 2 = for every launch of two
                                                                                           // blocks per workgroup, 0 = never (mustafar_tune(11, v))
-int g_small_waves = [] {   // one wave per SIMD: 4 x the CU count
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return (cus > 0 ? cus : 256) * 4;
-}();
+inline int small_waves()   // one wave per SIMD: 4 x the CU count (asked of the runtime at the first fused call, not when the library is loaded)
+{
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return (cus > 0 ? cus : 256) * 4;
+    }();
+    return n;
+}
 int g_spec_k_bytes = 0; // mustafar_tune(12, bytes): experiment, see OneArgs::spec_k_bytes
 int g_late_prio = 1;    // mustafar_tune(9, 0): no raised priority for a small last round of workgroups (experiments)
 int g_pair_slabs = 0;   // pair form, mustafar_tune(4, 1): a slab per pair instead of one per workgroup (kernel 1.1 us shorter at c3, row kernel 1.5 us longer)
@@ -4423,7 +4427,7 @@ int decode_attention(void* stream, const mustafar_cache_view& kc, const mustafar
                 // never touches, and a kernel with a private segment is launched with scratch (+1 % measured on the GQA-4 form); the
                 // extents instantiation has none and serves the same launch with every block in the base views)
                 if (!extents && G == 1) a.nb0 = ntb;
-                if (g_sb && per_wg == 2 && eng != 1 && onepass_lean_tbw() <= 0 && (g_small == 2 || (g_small == 1 && (int64_t)S1 * gy * kWaves <= g_small_waves))) {
+                if (g_sb && per_wg == 2 && eng != 1 && onepass_lean_tbw() <= 0 && (g_small == 2 || (g_small == 1 && (int64_t)S1 * gy * kWaves <= small_waves()))) {
                     // round 6: the form without a memory wait inside the phases, for launches that do not even put one wave on every SIMD (c1;
                     // Llama-3-8B 4k x batch 1): there its shorter chain wins 10 %; from two waves per SIMD on (8k x batch 1, c2) its extra
                     // v_readlane per step cost more than the waits they replace (profiles/r06_probes.txt item 3).  mustafar_tune(11, 2): always
