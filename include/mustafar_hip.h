@@ -85,6 +85,14 @@ int mustafar_compress_bitmap_key(void* stream, const void* x, int Bp, int t, int
                                  int64_t* head_off);
 int mustafar_compress_bitmap_value(void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
                                    int64_t* head_off);
+/* Pass 1 with a second copy of head_off for a host that WAITS for it (round 6; kernel/compression.py:308 `total_size = ....item()`: the reference
+ * synchronises here too).  host_mirror: B' + 1 int64 of device-visible host memory (hipHostMalloc / a pinned torch tensor) the caller has filled
+ * with a negative sentinel; the launch that computes head_off stores every entry there as well, each one aligned 8-byte system-scope store,
+ * BEFORE the launch that completes the offsets inside the blocks -- the caller polls until no entry is negative (or the stream has drained)
+ * and sizes the packed buffer ~15 us earlier than a device-to-host copy behind the stream would let it.  head_off (device) is written as by
+ * the plain calls: pass 2 reads that one.  key != 0: K tile geometry.  host_mirror == NULL: exactly mustafar_compress_bitmap_{key,value}. */
+int mustafar_compress_bitmap_mirrored(void* stream, const void* x, int Bp, int t, int D, int key, int64_t* bmp, int32_t* accum,
+                                      int64_t* head_off, int64_t* host_mirror);
 int mustafar_compress_pack_key(void* stream, const void* x, int Bp, int t, int D, const int64_t* bmp,
                                const int32_t* accum, const int64_t* head_off, void* nz_flat);
 int mustafar_compress_pack_value(void* stream, const void* x, int Bp, int t, int D, const int64_t* bmp,
@@ -210,6 +218,10 @@ int mustafar_decode_attention_view(void* stream, const mustafar_cache_view* k_ca
 int64_t mustafar_convert_scratch_bytes(int Bp, int t);
 int mustafar_convert_onepass(void* stream, const void* x, int Bp, int t, int D, int key, int64_t* bmp, int32_t* accum, int64_t* head_off,
                              void* regions, int32_t* overflow_flag, void* scratch);
+/* The same with a host mirror as mustafar_compress_bitmap_mirrored takes one (round 6), B' + 2 int64 here: [0 .. B'] = head_off,
+ * [B' + 1] = the value of *overflow_flag behind the compression launch (zero-extended).  Polled by the caller until no entry is negative. */
+int mustafar_convert_onepass_mirrored(void* stream, const void* x, int Bp, int t, int D, int key, int64_t* bmp, int32_t* accum,
+                                      int64_t* head_off, void* regions, int32_t* overflow_flag, void* scratch, int64_t* host_mirror);
 int mustafar_convert_pack(void* stream, const void* regions, int Bp, int t, int D, const int64_t* head_off, void* packed);
 int mustafar_cache_append_bitmap_key(void* stream, const void* x, int Bp, int t, int D, const mustafar_cache_view* dst,
                                      int old_tokens, int64_t* head_total);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mustafar_prune_magnitude": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32]),
     "mustafar_compress_bitmap_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mustafar_compress_bitmap_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mustafar_compress_bitmap_mirrored": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mustafar_compress_pack_key": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mustafar_compress_pack_value": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mustafar_cache_consolidate_extents": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "mustafar_compress_test_skip_publish": (_i32, [_i32]),
     "mustafar_convert_scratch_bytes": (_i64, [_i32, _i32]),
     "mustafar_convert_onepass": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mustafar_convert_onepass_mirrored": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mustafar_convert_pack": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
 }
 

@@ -6,9 +6,10 @@ Same arguments, same return types as kernel/compression.py:249-339 and :341-432:
 computed by the HIP kernels in csrc/compress.hip behind the C ABI (include/mustafar_hip.h).  One small
 device->host read (B'+1 int64 offsets) remains because the packed sizes define the shapes of the returned
 tensors; the reference needs 1 + 2B' `.item()` syncs for the same reason (:308, :333-334).  Two passes over the
-rows with the read between them (default); round 5 added the form that reads the rows ONCE (the one-pass compression
-launch into worst-case regions, the read behind it, a copy launch that packs the streams into the exact-size buffer):
-less GPU time, more wall time per call -- opt-in, MUSTAFAR_CONVERT=onepass.
+rows with the read between them (default below 768 Ki rows); round 5 added the form that reads the rows ONCE (the one-pass compression
+launch into worst-case regions, the read behind it, a copy launch that packs the streams into the exact-size buffer): the default from
+768 Ki rows on (MUSTAFAR_CONVERT=onepass / twopass force one).  Round 6: the host does not copy the offsets back, it polls a
+mirror of them in pinned memory (`_offsets_mirror`, `_await_offsets`).
 The per-head tensors are views of one packed buffer (the reference clones each slice, :335) and remember it: they are
 `StreamPiece`s, a tensor subclass whose only behaviour is that
     torch.cat(list of all the pieces of one buffer, in order)      (model :274, :314: once per layer and decode step)
@@ -92,8 +93,10 @@ def _append_piece(old: StreamPiece, new: StreamPiece) -> torch.Tensor:
 
 
 def pieces_of(flat: torch.Tensor, offs: List[int]) -> List[torch.Tensor]:
-    """Cut a packed buffer into per-head `StreamPiece`s (offs: B' + 1 boundaries in halfs).  One split call for the B' views and the
-    cheapest wrap per piece: at c3 (64 heads) this list is half of what a conversion call costs on the host (round 5: 2.3 -> 1.3 us per piece)."""
+    """Cut a packed buffer into per-head `StreamPiece`s (offs: B' + 1 boundaries in halfs).  At c3 (64 heads) this list was half of what a
+    conversion call costs on the host (round 5: 2.3 -> 1.3 us per piece).  Round 6: ONE split call that does not record the views for autograd
+    (`unsafe_split_with_sizes`: fp16 cache streams carry no gradient) and the fresh views RE-TYPED in place (`__class__` assignment: `StreamPiece`
+    adds no storage to `torch.Tensor`, so CPython allows it) instead of a second tensor object per piece through `_make_subclass`: ~0.4 us per piece."""
     bk = _Backing(flat, list(offs))
     n = len(offs) - 1
     if n == 0:
@@ -101,14 +104,14 @@ def pieces_of(flat: torch.Tensor, offs: List[int]) -> List[torch.Tensor]:
     if offs[0] != 0 or offs[-1] != flat.numel():
         views = [flat[offs[b]:offs[b + 1]] for b in range(n)]
     else:
-        views = flat.split([offs[b + 1] - offs[b] for b in range(n)])
-    mk = torch.Tensor._make_subclass
-    out = []
-    for b, v in enumerate(views):
-        p = mk(StreamPiece, v)
+        views = list(torch.unsafe_split_with_sizes(flat, [offs[b + 1] - offs[b] for b in range(n)]))
+    for b, p in enumerate(views):
+        if type(p) is torch.Tensor:
+            p.__class__ = StreamPiece
+        else:                                   # `flat` itself a subclass: leave its type system alone
+            p = views[b] = torch.Tensor._make_subclass(StreamPiece, p)
         p._bk, p._ix = bk, b
-        out.append(p)
-    return out
+    return views
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -141,8 +144,40 @@ def prune_magnitude(x: torch.Tensor, target_sparsity: float, out: torch.Tensor |
     return out.view(x.shape)
 
 
+import threading as _threading
+
+_mirrors = _threading.local()   # per host thread: {(device index, B'): (pinned int64 [B' + 1], its numpy view)}
+
+
+def _offsets_mirror(dev: torch.device, B: int):
+    """Pinned (device-visible) host memory the bitmap launch mirrors head_off into.  One per thread, device and head count, reused from call to
+    call: only the launch of the CURRENT call writes it, and that call does not return before it has seen every entry."""
+    pool = _mirrors.__dict__.setdefault("pool", {})
+    key = (dev.index, B)
+    m = pool.get(key)
+    if m is None:
+        pin = torch.empty((B + 1,), dtype=torch.int64, pin_memory=True)
+        m = pool[key] = (pin, pin.numpy())
+    return m
+
+
+def _await_offsets(arr, stream: torch.cuda.Stream) -> List[int]:
+    """Spin until no entry of the mirror is the negative sentinel.  Bounded by the stream: once it has drained every store has landed (a
+    kernel's stores to host memory are complete when it is), so entries still negative then are an error, not a wait."""
+    spins = 0
+    while arr.min() < 0:
+        spins += 1
+        if spins % 256 == 0 and stream.query():
+            if arr.min() < 0:
+                raise RuntimeError("mustafar: the stream drained and the compression launch left no stream offsets behind")
+            break
+    return arr.tolist()
+
+
 def _convert_twopass(x: torch.Tensor, which: str) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
-    """Round 1-4 form: bitmaps + offsets (first pass over the rows), host read of the sizes, packed streams (second pass)."""
+    """Round 1-4 form: bitmaps + offsets (first pass over the rows), host read of the sizes, packed streams (second pass).
+    Round 6: the sizes reach the host through a mirror in pinned memory the host polls (`mustafar_compress_bitmap_mirrored`) instead of a
+    device-to-host copy behind the stream: the second pass is queued ~15 us earlier.  MUSTAFAR_CONVERT_SYNC=copy keeps the copy."""
     B, M, N = x.shape
     dev = x.device
     tiles = M * N // 64
@@ -150,12 +185,21 @@ def _convert_twopass(x: torch.Tensor, which: str) -> Tuple[torch.Tensor, torch.T
     accum = torch.empty((B, tiles + 1), dtype=torch.int32, device=dev)
     head_off = torch.empty((B + 1,), dtype=torch.int64, device=dev)
     L = _lib.load()
-    st = _stream_ptr(dev)
     with torch.cuda.device(dev):
-        err = getattr(L, f"mustafar_compress_bitmap_{which}")(st, x.data_ptr(), B, M, N, bitmaps.data_ptr(),
-                                                              accum.data_ptr(), head_off.data_ptr())
-        _lib.check(err, f"mustafar_compress_bitmap_{which}")
-        offs = head_off.cpu().tolist()   # the one host sync: sizes of the returned tensors
+        stream = torch.cuda.current_stream(dev)
+        st = stream.cuda_stream
+        if _CONVERT_SYNC_COPY:
+            err = getattr(L, f"mustafar_compress_bitmap_{which}")(st, x.data_ptr(), B, M, N, bitmaps.data_ptr(),
+                                                                  accum.data_ptr(), head_off.data_ptr())
+            _lib.check(err, f"mustafar_compress_bitmap_{which}")
+            offs = head_off.cpu().tolist()   # the one host sync: sizes of the returned tensors
+        else:
+            pin, arr = _offsets_mirror(dev, B)
+            arr.fill(-1)
+            err = L.mustafar_compress_bitmap_mirrored(st, x.data_ptr(), B, M, N, 1 if which == "key" else 0, bitmaps.data_ptr(),
+                                                      accum.data_ptr(), head_off.data_ptr(), pin.data_ptr())
+            _lib.check(err, "mustafar_compress_bitmap_mirrored")
+            offs = _await_offsets(arr, stream)   # the one host wait: sizes of the returned tensors
         packed = torch.empty((offs[-1],), dtype=torch.float16, device=dev)
         err = getattr(L, f"mustafar_compress_pack_{which}")(st, x.data_ptr(), B, M, N, bitmaps.data_ptr(),
                                                             accum.data_ptr(), head_off.data_ptr(),
@@ -166,15 +210,22 @@ def _convert_twopass(x: torch.Tensor, which: str) -> Tuple[torch.Tensor, torch.T
 
 import os as _os
 
-# Which form a conversion call takes.  MEASURED (round 5, c3: 64 heads x 7936 tokens, wall time of a call): two passes 188 us, one pass 215 us -- the
-# call is bound by the host (B' tensor views to build for the result list), the two-pass form has LESS device work in front of the host read
-# (37 us of counting against 65 us of counting + packing) and hides its second pass behind the host's list building.  Default: two passes;
-# MUSTAFAR_CONVERT=onepass selects the one-read form (equal results, tests/test_gpu_parity.py).
-_CONVERT_ONEPASS = _os.environ.get("MUSTAFAR_CONVERT", "") == "onepass" and _os.environ.get("MUSTAFAR_COMPRESS", "") != "twopass"
+# Which form a conversion call takes.  MEASURED (round 6, wall time of a call in us, two passes / one pass, key and value; tools/probes/convert_breakdown.py,
+# profiles/r06_convert_breakdown.txt): c1 59 / 68 and 65 / 62, c2 56 / 76 and 54 / 67, c3 (64 heads x 7936 tokens) 99 / 114 and 101 / 106, c4 (32 x 32512)
+# 168 / 153 and 238 / 139, c5 (128 x 16128) 330 / 284 and 472 / 279.  A call is device time + one host wait: the two-pass form has LESS device work in front
+# of the wait (35 us of counting against 65 us of counting + packing at c3), the one-pass form reads the rows once and its copy launch beats the second pass
+# from ~1 M rows on (the second pass of V runs at 2 TB/s there).  Default: two passes below 768 Ki rows, one pass from there on; MUSTAFAR_CONVERT=onepass /
+# twopass selects one form for every size (equal results, tests/test_gpu_parity.py).  (Round 5, before the list of pieces was made cheap and the
+# wait was a device-to-host copy: 188 / 215 at c3.)
+_CONVERT_SYNC_COPY = _os.environ.get("MUSTAFAR_CONVERT_SYNC", "") == "copy"
+_CONVERT_FORM = {"onepass": 1, "twopass": 2}.get(_os.environ.get("MUSTAFAR_CONVERT", ""), 0)
+if _os.environ.get("MUSTAFAR_COMPRESS", "") == "twopass":
+    _CONVERT_FORM = 2
+_CONVERT_ONEPASS_ROWS = 768 * 1024
 convert_fallbacks = 0   # conversions repeated through the two-pass form because a block of the one-pass launch gave up waiting (never seen)
 
 
-def _convert(inputs: torch.Tensor, which: str, onepass: bool = False) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
+def _convert(inputs: torch.Tensor, which: str, onepass: bool | None = None) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
     """`onepass` (or MUSTAFAR_CONVERT=onepass; round 5): ONE read of the rows.  The one-pass compression launch writes bitmaps, offsets and every head's stream (into regions of
     worst-case size), the sizes are read on the host BEHIND that work (the reference's return type needs them: compression.py:308),
     and one copy launch packs the regions into the exact-size buffer.  Rounds 1-4 read the rows twice with the host read in between."""
@@ -186,7 +237,9 @@ def _convert(inputs: torch.Tensor, which: str, onepass: bool = False) -> Tuple[t
     if inputs.dtype != torch.float16 or N != 128:
         raise RuntimeError("convert_*_batched expects float16 [B', t, 128]")
     x = inputs.contiguous()
-    if not (_CONVERT_ONEPASS or onepass) or B * M * (N // 8) > 0xffffffff:
+    if onepass is None:
+        onepass = _CONVERT_FORM == 1 or (_CONVERT_FORM == 0 and B * M >= _CONVERT_ONEPASS_ROWS)
+    if not onepass or B * M * (N // 8) > 0xffffffff:
         return _convert_twopass(x, which)
     dev = x.device
     tiles = M * N // 64
@@ -198,10 +251,19 @@ def _convert(inputs: torch.Tensor, which: str, onepass: bool = False) -> Tuple[t
     with torch.cuda.device(dev):
         regions = torch.empty((B * M * N,), dtype=torch.float16, device=dev)    # worst case: nothing pruned
         scratch = torch.empty((int(L.mustafar_convert_scratch_bytes(B, M)),), dtype=torch.uint8, device=dev)
-        err = L.mustafar_convert_onepass(st, x.data_ptr(), B, M, N, 1 if which == "key" else 0, bitmaps.data_ptr(), accum.data_ptr(),
-                                         status.data_ptr(), regions.data_ptr(), status.data_ptr() + 8 * (B + 1), scratch.data_ptr())
-        _lib.check(err, "mustafar_convert_onepass")
-        host = status.cpu().tolist()     # the one host sync: sizes of the returned tensors (and the flag)
+        if _CONVERT_SYNC_COPY:
+            err = L.mustafar_convert_onepass(st, x.data_ptr(), B, M, N, 1 if which == "key" else 0, bitmaps.data_ptr(), accum.data_ptr(),
+                                             status.data_ptr(), regions.data_ptr(), status.data_ptr() + 8 * (B + 1), scratch.data_ptr())
+            _lib.check(err, "mustafar_convert_onepass")
+            host = status.cpu().tolist()     # the one host sync: sizes of the returned tensors (and the flag)
+        else:
+            pin, arr = _offsets_mirror(dev, B + 1)
+            arr.fill(-1)
+            err = L.mustafar_convert_onepass_mirrored(st, x.data_ptr(), B, M, N, 1 if which == "key" else 0, bitmaps.data_ptr(), accum.data_ptr(),
+                                                      status.data_ptr(), regions.data_ptr(), status.data_ptr() + 8 * (B + 1), scratch.data_ptr(),
+                                                      pin.data_ptr())
+            _lib.check(err, "mustafar_convert_onepass_mirrored")
+            host = _await_offsets(arr, torch.cuda.current_stream(dev))     # the one host wait: sizes of the returned tensors (and the flag)
         if host[B + 1] & 0xffffffff:
             convert_fallbacks += 1
             return _convert_twopass(x, which)

@@ -286,7 +286,12 @@ __global__ __launch_bounds__(kThreads) void block_scan_kernel(Side s0, Side s1, 
 }
 
 // head_off[h] = exclusive prefix of totals (compression.py:303-304), head_off[B'] = grand total.  In place, one workgroup.
-__global__ __launch_bounds__(kThreads) void head_offsets_kernel(int64_t* __restrict__ head_off, int Bp)
+// `mirror` (or null; round 6): the same B' + 1 values stored a second time, at SYSTEM scope, into device-visible HOST memory -- the caller of
+// mustafar_compress_bitmap_mirrored polls it instead of copying head_off back behind the stream (each value one aligned 8-byte store: a
+// reader sees an entry's old or new value, never a torn one, whatever order the entries arrive in).
+// `flag` (with a mirror only): a device word the launches in front of this one have finished with; mirror[B' + 1] = its value, zero-extended.
+__global__ __launch_bounds__(kThreads) void head_offsets_kernel(int64_t* __restrict__ head_off, int Bp, int64_t* mirror = nullptr,
+                                                                const int32_t* flag = nullptr)
 {
     __shared__ int64_t s_wave[kWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -305,11 +310,20 @@ __global__ __launch_bounds__(kThreads) void head_offsets_kernel(int64_t* __restr
         int64_t add = carry;
         for (int w = 0; w < wave; w++) add += s_wave[w];
         const int64_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        if (i < Bp) head_off[i] = v - own + add;
+        if (i < Bp) {
+            head_off[i] = v - own + add;
+            if (mirror) __hip_atomic_store(mirror + i, v - own + add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         carry += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) head_off[Bp] = carry;
+    if (threadIdx.x == 0) {
+        head_off[Bp] = carry;
+        if (mirror) {
+            __hip_atomic_store(mirror + Bp, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (flag) __hip_atomic_store(mirror + Bp + 1, (int64_t)(uint32_t)*flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ pack
@@ -831,7 +845,7 @@ __global__ __launch_bounds__(kD) void block_fixup_kernel(const int32_t* __restri
 }
 
 int bitmap_common(bool key, void* stream, const void* x, int Bp, int t, int D, int64_t* bmp, int32_t* accum,
-                  int64_t* totals, Rows rows, bool exclusive_prefix)
+                  int64_t* totals, Rows rows, bool exclusive_prefix, int64_t* mirror = nullptr)
 {
     if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || !totals) return MUSTAFAR_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -847,8 +861,10 @@ int bitmap_common(bool key, void* stream, const void* x, int Bp, int t, int D, i
     Side s{static_cast<const uint16_t*>(x), (int64_t)t * kD, bmp, accum, nullptr, totals, nullptr, nullptr, nullptr, rows, 0, 0, key ? 1 : 0};
     int err = launch_meta(st, &s, 1, Bp, t, blk, nullptr, false);
     if (!err) {
+        // (the head offsets need the block scan's totals only: in front of the fix-up, so that a caller polling the mirror has them while
+        // the fix-up still runs)
+        if (exclusive_prefix) head_offsets_kernel<<<1, kThreads, 0, st>>>(totals, Bp, mirror);
         block_fixup_kernel<<<dim3(ntb, Bp), kD, 0, st>>>(blk, accum, rows);
-        if (exclusive_prefix) head_offsets_kernel<<<1, kThreads, 0, st>>>(totals, Bp);
         err = (int)hipGetLastError();
     }
     if (pooled) {
@@ -920,6 +936,10 @@ int mustafar_compress_bitmap_value(void* stream, const void* x, int Bp, int t, i
                                    int64_t* head_off)
 { return bitmap_common(false, stream, x, Bp, t, D, bmp, accum, head_off, fresh_rows(t), true); }
 
+int mustafar_compress_bitmap_mirrored(void* stream, const void* x, int Bp, int t, int D, int key, int64_t* bmp, int32_t* accum, int64_t* head_off,
+                                      int64_t* host_mirror)
+{ return bitmap_common(key != 0, stream, x, Bp, t, D, bmp, accum, head_off, fresh_rows(t), true, host_mirror); }
+
 int mustafar_compress_pack_key(void* stream, const void* x, int Bp, int t, int D, const int64_t* bmp,
                                const int32_t* accum, const int64_t* head_off, void* nz_flat)
 { return pack_common(true, stream, x, Bp, t, D, bmp, accum, head_off, nullptr, nz_flat, fresh_rows(t)); }
@@ -935,8 +955,8 @@ int64_t mustafar_convert_scratch_bytes(int Bp, int t)
     return (int64_t)Bp * (t / 64) * (int64_t)sizeof(uint64_t) + (((int64_t)Bp * 4 + 15) & ~(int64_t)15);
 }
 
-int mustafar_convert_onepass(void* stream, const void* x, int Bp, int t, int D, int key, int64_t* bmp, int32_t* accum, int64_t* head_off,
-                             void* regions, int32_t* overflow_flag, void* scratch)
+int mustafar_convert_onepass_mirrored(void* stream, const void* x, int Bp, int t, int D, int key, int64_t* bmp, int32_t* accum, int64_t* head_off,
+                                      void* regions, int32_t* overflow_flag, void* scratch, int64_t* host_mirror)
 {
     if (D != kD || Bp < 1 || t < 64 || (t & 63) || !x || !bmp || !accum || !head_off || !regions || !overflow_flag || !scratch ||
         (int64_t)Bp * t * (kD / 8) > 0xffffffffll)   // (stream starts in 16-byte units are 32-bit, as in the format)
@@ -952,9 +972,13 @@ int mustafar_convert_onepass(void* stream, const void* x, int Bp, int t, int D, 
     const Side s{static_cast<const uint16_t*>(x), (int64_t)t * kD, bmp, accum, nullptr, head_off, nullptr, nz_off, static_cast<uint16_t*>(regions),
                  fresh_rows(t), region_halfs, 0, key ? 1 : 0};
     compress_block_kernel<<<dim3(ntb, Bp, 1), 64, 0, st>>>(s, s, ntb, gran, overflow_flag, take_skip_publish());
-    head_offsets_kernel<<<1, kThreads, 0, st>>>(head_off, Bp);
+    head_offsets_kernel<<<1, kThreads, 0, st>>>(head_off, Bp, host_mirror, overflow_flag);
     return (int)hipGetLastError();
 }
+
+int mustafar_convert_onepass(void* stream, const void* x, int Bp, int t, int D, int key, int64_t* bmp, int32_t* accum, int64_t* head_off,
+                             void* regions, int32_t* overflow_flag, void* scratch)
+{ return mustafar_convert_onepass_mirrored(stream, x, Bp, t, D, key, bmp, accum, head_off, regions, overflow_flag, scratch, nullptr); }
 
 int mustafar_convert_pack(void* stream, const void* regions, int Bp, int t, int D, const int64_t* head_off, void* packed)
 {

@@ -238,12 +238,44 @@ def test_one_read_conversion_equals_the_two_pass_form(which):
     dense[dense == 0] = 1
     cases.append(dense)
     for x in cases:
-        a_bmp, a_acc, a_nz = comp._convert(x, which)
+        a_bmp, a_acc, a_nz = comp._convert(x, which, onepass=False)
         b_bmp, b_acc, b_nz = comp._convert(x, which, onepass=True)
         assert torch.equal(a_bmp, b_bmp) and torch.equal(a_acc, b_acc) and len(a_nz) == len(b_nz)
         for p, q in zip(a_nz, b_nz):
             assert torch.equal(p.view(torch.int16), q.view(torch.int16))
         assert torch.cat(b_nz).data_ptr() == b_nz[0].data_ptr() if b_nz[0].numel() else True     # (pieces of one buffer: the free concatenation)
+        # round 6: the sizes reach the host through a polled mirror in pinned memory (default) or a device-to-host copy: the same results
+        comp._CONVERT_SYNC_COPY = True
+        try:
+            for form in (False, True):
+                c_bmp, c_acc, c_nz = comp._convert(x, which, onepass=form)
+                assert torch.equal(a_bmp, c_bmp) and torch.equal(a_acc, c_acc) and [p.numel() for p in c_nz] == [p.numel() for p in a_nz]
+                assert torch.equal(torch.cat(c_nz).view(torch.int16), torch.cat(a_nz).view(torch.int16))
+        finally:
+            comp._CONVERT_SYNC_COPY = False
+    assert comp.convert_fallbacks == 0
+
+
+def test_conversion_form_by_size_and_the_mirror_reused_across_calls():
+    """The default form is chosen by the number of rows (two passes below 768 Ki rows, one pass from there on: compression.py); calls of different
+    head counts and forms on one thread share the pinned mirrors of the stream offsets without seeing each other's values."""
+    from mustafar_amd import compression as comp
+    torch.manual_seed(5)
+    small = torch.from_numpy(make_cache("key", 4, 256, 128, 0.7, 11)["pruned"]).to(DEV)
+    old = comp._CONVERT_ONEPASS_ROWS
+    try:
+        outs = []
+        for rows_at in (1 << 40, 1):            # two passes, then one pass, through the PUBLIC entry point
+            comp._CONVERT_ONEPASS_ROWS = rows_at
+            for x in (small, small[:3], small[:, :64], small):
+                bmp, acc, nz = comp.convert_key_batched(x)
+                outs.append((x.shape, bmp.clone(), acc.clone(), [p.clone() for p in nz]))
+        half = len(outs) // 2
+        for (sa, ba, aa, na), (sb, bb, ab, nb) in zip(outs[:half], outs[half:]):
+            assert sa == sb and torch.equal(ba, bb) and torch.equal(aa, ab) and all(torch.equal(p.view(torch.int16), q.view(torch.int16)) for p, q in zip(na, nb))
+        assert torch.equal(outs[0][1], outs[3][1]) and torch.equal(outs[0][2], outs[3][2])
+    finally:
+        comp._CONVERT_ONEPASS_ROWS = old
     assert comp.convert_fallbacks == 0
 
 
