@@ -355,7 +355,8 @@ int mustafar_last_decode_choice(void);
 /* Tuning knobs for the measurement scripts under tools/ (launch shapes of the one-pass forms); not an operator interface.
  * Round 6: knob 11 = the small-launch kernel (0 never, 1 launches of two blocks per workgroup that put at most one wave on every SIMD -- the
  * default, 2 every launch of two blocks per workgroup); knob 12 = bytes of key stream per block for the speculative first-chunk request
- * (an experiment that measured slower; 0 = off, the default). */
+ * (an experiment that measured slower; 0 = off, the default); knob 13 = Value_SplitK_API with N_Global = 8 on the lean kernel, the pad rows read by
+ * workgroups of their own behind the row-0 workgroups (1, the default) or on round 1's kernel (0). */
 int mustafar_tune(int knob, int value);
 
 /*

@@ -569,6 +569,57 @@ __device__ __forceinline__ uint32_t pad_row_mask(const h16* __restrict__ dense, 
     return all;
 }
 
+// The same question for a GROUP of consecutive token chunks (round 6, value_lean_kernel's pad workgroups): bit 8 c + n of the result is set iff pad row
+// n (1 <= n < N) holds a non-zero for any of the G heads over chunk c of [col0, col0 + ncols) (chunks of chunk_cols columns, at most four; ncols % 8 == 0).
+// Written for memory-level parallelism -- a thread's loads are independent and MUSTAFAR_PAD_UNROLL of them are in flight per trip; a row's slice is one contiguous run.
+#ifndef MUSTAFAR_PROBE_N1AS8
+#define MUSTAFAR_PROBE_N1AS8 0    // (timing probe, with MUSTAFAR_PROBE_NOPADWG: 8-row calls run the N = 1 instantiation on row 0 at the 8-row pitch of the dense operand; the output layout is wrong)
+#endif
+#ifndef MUSTAFAR_PAD_UNROLL
+#define MUSTAFAR_PAD_UNROLL 4
+#endif
+#ifndef MUSTAFAR_PAD_GROUP
+#define MUSTAFAR_PAD_GROUP 4      // token chunks per pad workgroup (at most 4: a byte of the mask per chunk)
+#endif
+template <int G, int N>
+__device__ __forceinline__ uint32_t pad_group_mask(const h16* __restrict__ dense, int64_t row_len, int bh0, int col0, int ncols, int chunk_cols,
+                                                   uint32_t* sh_mask)
+{
+    if (threadIdx.x == 0) *sh_mask = 0u;
+    __syncthreads();
+    const int V = ncols / 8;              // 16-byte vectors of a row's slice
+    constexpr int R = G * (N - 1);        // rows
+    const int nthr = (int)blockDim.x;
+    int r = (int)threadIdx.x / V, k = (int)threadIdx.x - r * V;
+    const int dr = nthr / V, dk = nthr - dr * V;
+    uint32_t mine = 0;
+    while (r < R) {
+        u32x4 v[MUSTAFAR_PAD_UNROLL];
+        int rr[MUSTAFAR_PAD_UNROLL], kk[MUSTAFAR_PAD_UNROLL];
+#pragma unroll
+        for (int i = 0; i < MUSTAFAR_PAD_UNROLL; i++) {
+            rr[i] = r;
+            kk[i] = k;
+            v[i] = u32x4{0u, 0u, 0u, 0u};
+            if (r < R) {
+                const int h = r / (N - 1), n = 1 + r % (N - 1);
+                v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dense + ((int64_t)(bh0 + h) * N + n) * row_len + col0 + k * 8));
+            }
+            r += dr;
+            k += dk;
+            if (k >= V) { k -= V; r++; }
+        }
+#pragma unroll
+        for (int i = 0; i < MUSTAFAR_PAD_UNROLL; i++)
+            if ((v[i].x | v[i].y | v[i].z | v[i].w) & 0x7fff7fffu) mine |= 1u << (8 * ((kk[i] * 8) / chunk_cols) + 1 + rr[i] % (N - 1));   // (-0.0 counts as zero)
+    }
+    if (mine) atomicOr(sh_mask, mine);
+    __syncthreads();
+    const uint32_t all = *sh_mask;
+    __syncthreads();   // sh_mask lives in the stage area: nobody may stage before everybody has read it
+    return all;
+}
+
 // ------------------------------------------------------------------------------------------------ key
 // The 5 stream offsets that bound the 4 chunks of a 64-token block (idx[0], idx[32], ..., idx[128]), fetched by
 // lanes 0..4 with one vector load; bnd_get() broadcasts one of them into an SGPR (v_readlane).
@@ -1172,23 +1223,33 @@ __global__ MUSTAFAR_VALUE_BOUNDS void value_spmv_kernel(
 
 // out[bh, n, c] = fp16( sum_s ws[s, bh, n, c] ), pad rows only from the slabs whose row mask has them.
 // (the role of the reference's SplitK_Reduction, Reduction_Kernel.cuh:26-48, with fp32 partials)
-// One workgroup per output row (bh, n): thread = (channel, slab parity); independent loads, LDS fold of the halves.
+// One workgroup per head row bh (round 6; rounds 1-5: one per output row (bh, n) -- 8 x the workgroups for the hook's padded calls, seven of
+// eight of them reading S flag words to learn they have nothing to add: 7.8 us against 4.6 for N = 1): thread = (channel, slab parity),
+// independent loads, LDS fold of the halves; row 0 first, then -- N > 1 -- the OR of the head group's S row masks decides in one step whether
+// any pad row holds anything (the hook's never do: 7 x 128 zeros are written), and only then the rows are folded one by one.
 __global__ __launch_bounds__(256) void value_combine_kernel(const float* __restrict__ ws,
                                                             const uint32_t* __restrict__ flags, h16* __restrict__ out,
                                                             int BH, int N, int S, int groups, int G)
 {
     __shared__ float part[kD];
-    const int row = blockIdx.x;            // bh * N + n
-    const int n = row % N, bh = row / N;
+    __shared__ uint32_t any_rows;
+    const int bh = blockIdx.x;
     const int c = threadIdx.x & (kD - 1), par = threadIdx.x >> 7;
     const int hb_per_kv = groups / G;
     const int y  = (bh / groups) * hb_per_kv + (bh % groups) / G;   // blockIdx.y of the producer
     const int gy = (BH / groups) * hb_per_kv;
     const int64_t total = (int64_t)BH * N * kD;
-    const float* src = ws + (int64_t)row * kD + c;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = par;
-    if (n == 0) {
+    uint32_t mine = 0;
+    if (N > 1) {
+        if (threadIdx.x == 0) any_rows = 0u;
+#ifndef MUSTAFAR_PROBE_NOPADWG   // (that timing probe leaves the masks unwritten: take them as "row 0 only")
+        for (int k = threadIdx.x; k < S; k += 256) mine |= flags[k * gy + y];   // (requested in front of row 0's loads)
+#endif
+    }
+    {
+        const float* src = ws + (int64_t)bh * N * kD + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = par;
         for (; k + 6 < S; k += 8) {
             s0 += src[(int64_t)k * total];
             s1 += src[(int64_t)(k + 2) * total];
@@ -1196,14 +1257,31 @@ __global__ __launch_bounds__(256) void value_combine_kernel(const float* __restr
             s3 += src[(int64_t)(k + 6) * total];
         }
         for (; k < S; k += 2) s0 += src[(int64_t)k * total];
-    } else {
-        for (; k < S; k += 2)
-            if ((flags[k * gy + y] >> n) & 1u) s0 += src[(int64_t)k * total];
+        const float s = (s0 + s1) + (s2 + s3);
+        if (par) part[c] = s;
+        __syncthreads();
+        if (!par) out[(int64_t)bh * N * kD + c] = (h16)(s + part[c]);
     }
-    const float s = (s0 + s1) + (s2 + s3);
-    if (par) part[c] = s;
+    if (N == 1) return;
+    if (mine & ~1u) atomicOr(&any_rows, mine);
     __syncthreads();
-    if (!par) out[(int64_t)row * kD + c] = (h16)(s + part[c]);
+    const uint32_t live = any_rows;
+    if (!(live & ~1u)) {   // no slab holds a pad row: zeros
+        for (int o = threadIdx.x; o < (N - 1) * kD; o += 256) out[((int64_t)bh * N + 1) * kD + o] = (h16)0.f;
+        return;
+    }
+    for (int n = 1; n < N; n++) {
+        float s = 0.f;
+        if ((live >> n) & 1u) {
+            const float* src = ws + ((int64_t)bh * N + n) * kD + c;
+            for (int k = par; k < S; k += 2)
+                if ((flags[k * gy + y] >> n) & 1u) s += src[(int64_t)k * total];
+        }
+        __syncthreads();   // (part: the row before is folded)
+        if (par) part[c] = s;
+        __syncthreads();
+        if (!par) out[((int64_t)bh * N + n) * kD + c] = (h16)(s + part[c]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ fused decode glue
@@ -3766,6 +3844,9 @@ __global__ MUSTAFAR_LP_BOUNDS void key_lean_kernel(
 #ifndef MUSTAFAR_VL_STRIDE
 #define MUSTAFAR_VL_STRIDE 1   // the probabilities' rows through one base pointer + a scalar offset per head (0: a pointer per head, round 4 / 5a)
 #endif
+#ifndef MUSTAFAR_VL_PFCOEF
+#define MUSTAFAR_VL_PFCOEF 1   // the probabilities of a pair's blocks prefetched into L2 at the top of the trip (round 6; 0: not)
+#endif
 #if MUSTAFAR_VL_STRIDE
 #define MUSTAFAR_VL_COEF CoefStride
 #else
@@ -3799,13 +3880,30 @@ __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
             return;
         }
     }
-    const int by = blockIdx.y - (WIN && wa.rows > 0 ? wa.rows : 0);
+    // N > 1 (round 6): the pad rows have workgroups of their OWN.  Grid rows [0, gy) -- dispatched first -- compute row 0 and never look at the
+    // pad rows: they are the N = 1 launch.  The rows behind them are pad workgroups: one per head group and kPadGroup consecutive token chunks;
+    // it reads its slice of the G x (N - 1) pad rows (2 KiB runs, every load of a thread in flight at once), publishes the row masks of its
+    // chunks' slabs and computes, chunk by chunk, the rows that hold a non-zero.  With the hook's zero pads (model :313) it reads ~14 vectors per
+    // thread and leaves -- in the tail of the launch, where the chip has wave slots to spare.  (Rounds 4-5: every workgroup read its pad slice in
+    // FRONT of row 0 -- three barriers and a trip to memory before its first stream request: c3, N = 8, 48.4 us per call against 26 for N = 1.)
+    constexpr int kPadGroup = MUSTAFAR_PAD_GROUP;
     const int hb_per_kv = groups / G;
+    const int gy_main = N > 1 ? (BH / groups) * hb_per_kv : (int)gridDim.y;
+    const bool pad_wg = N > 1 && (int)blockIdx.y >= gy_main;
+    int by = (int)blockIdx.y - (WIN && wa.rows > 0 ? wa.rows : 0), slab0 = (int)blockIdx.x, nck = 1;
+    if constexpr (N > 1) {
+        if (pad_wg) {
+            const int S = (int)gridDim.x, S4 = (S + kPadGroup - 1) / kPadGroup;
+            const int j = ((int)blockIdx.y - gy_main) * S + (int)blockIdx.x;
+            if (j >= gy_main * S4) { MUSTAFAR_TRACE_END(); return; }   // (the pad rows of the grid are rounded up to whole rows)
+            by = j / S4;
+            slab0 = (j - by * S4) * kPadGroup;
+            nck = min(kPadGroup, S - slab0);
+        }
+    }
     const int kvh = by / hb_per_kv;
     const int bh0 = kvh * groups + (by % hb_per_kv) * G;
     const int ntb = T >> 6;
-    const int tb0 = blockIdx.x * tb_per_wg;
-    const int tb_end = min(ntb, tb0 + tb_per_wg);
     const int64_t tiles = (int64_t)ntb * kTilesPerTb;
     const int pair = wave >> 1;
     const bool odd = wave & 1;
@@ -3815,15 +3913,14 @@ __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
     unsigned char* lds = smem + wave * kStageBytes;
     const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(lds);
     float* red = reinterpret_cast<float*>(smem);   // [kWaves][G][64], overlays the stage windows
-    float* ws_slab = ws + (int64_t)blockIdx.x * BH * N * kD;
 
-    uint32_t rows = 1u;
-    if constexpr (N > 1) {
-        rows |= pad_row_mask<G>(p, ldb, bh0, N, tb0 * 64, (tb_end - tb0) * 64, reinterpret_cast<uint32_t*>(smem));
-        if (!direct && threadIdx.x == 0) flags[blockIdx.x * gridDim.y + by] = rows;   // (no window rows when N > 1)
-    }
+    // rows [n_lo, n_hi) of the token chunk `slab` (rows: which of them hold a non-zero; the others are written as zeros in a direct launch, skipped otherwise)
+    auto run_chunk = [&](const int slab, const uint32_t rows, const int n_lo, const int n_hi) {
+    const int tb0 = slab * tb_per_wg;
+    const int tb_end = min(ntb, tb0 + tb_per_wg);
+    float* ws_slab = ws + (int64_t)slab * BH * N * kD;
 #pragma unroll 1
-    for (int n = 0; n < N; n++) {
+    for (int n = n_lo; n < n_hi; n++) {
         const bool live = (rows >> n) & 1u;
         if (!live && !direct) continue;   // the combine pass skips this row of this slab
         float acc[G];
@@ -3860,6 +3957,13 @@ __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
 #pragma unroll
                 for (int h = 0; h < G; h++) cb.p[h] = p + ((int64_t)(bh0 + h) * N + n) * ldb + (int64_t)tb * 64;
 #endif
+#if MUSTAFAR_VL_STRIDE && MUSTAFAR_VL_PFCOEF
+                // round 6: the probabilities of these (<= 2) blocks, 128 bytes per block and head, asked into L2 by a vector load NOW -- the steps read them with
+                // scalar loads inside their one wait, and a row the softmax kernel wrote a moment ago (or one 127 KiB from its neighbour: the hook's 8-row
+                // operand) is not in L2 when they do: us per call at c3, same box, without / with: 8 rows 34.0-34.3 / 28.0-28.2, one row 26.1-26.9 / 24.9-25.0; c4 51.0 / 49.6 and 45.0 / 41.4-42.9 (profiles/r06_probes.txt item 9).  Lanes 0..2G-1: (head, block); behind the
+                // bounds and the bitmap lines in program order, so no wait of theirs covers it.
+                const uint32_t pfP = ld_at(cb.base, (uint32_t)(((lane & (2 * G - 1)) >> 1) * head_bytes + ((lane & 1) && two ? 128u : 0u)));
+#endif
                 if (two) {
                     uint32_t pfB = 0;
                     auto reqB = [&]() { pfB = ld_at(vbt + kTilesPerTb, off_bmp); };
@@ -3870,6 +3974,9 @@ __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
                     lean_block_phase<0, 0, true, 0, 2, G, MUSTAFAR_VL_COEF<G>>(lds, lds_addr, vbt, vit, vn, cb, bnd, lane, acc, acc MUSTAFAR_PTRACE_ARG);
                 }
                 prefetch_done(pfA);
+#if MUSTAFAR_VL_STRIDE && MUSTAFAR_VL_PFCOEF
+                prefetch_done(pfP);
+#endif
                 if (MUSTAFAR_PRIO) __builtin_amdgcn_s_setprio(0);   // (the first blocks are done)
             }
         }
@@ -3886,6 +3993,36 @@ __global__ MUSTAFAR_LP_BOUNDS void value_lean_kernel(
             else        ws_slab[row * kD + half * 64 + l] = sum;
         }
         if constexpr (N > 1) __syncthreads();
+    }
+    };
+
+    if constexpr (N > 1) {
+        // ONE inlined copy of run_chunk for both kinds of workgroup (two copies: 188 scalar-spill reloads against 37 in the N = 1 instantiation, 7 us at c3)
+        uint32_t all = 1u;   // row-0 workgroup: chunk 0 of its "group" = its own slab, row 0
+        int n_lo = 0, n_hi = 1;
+        if (pad_wg) {
+            const int cw = tb_per_wg * 64;                              // tokens (columns of the dense operand) per chunk
+            const int col0 = slab0 * cw, ncols = min(T, col0 + nck * cw) - col0;
+#ifdef MUSTAFAR_PROBE_NOPADREAD   // (timing probe: the pad workgroups are dispatched and publish "nothing live" without reading anything -- wrong for non-zero pads)
+            all = 0u;
+            (void)col0; (void)ncols;
+#else
+            all = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)pad_group_mask<G, N>(p, ldb, bh0, col0, ncols, cw, reinterpret_cast<uint32_t*>(smem)));   // bits 8 c + n: pad row n over chunk c
+#endif
+            if (!direct && (int)threadIdx.x < nck)
+                flags[(slab0 + (int)threadIdx.x) * gy_main + by] = ((all >> (8 * threadIdx.x)) & 0xfeu) | 1u;   // (row 0: every slab, always; no window rows when N > 1)
+            if (all == 0u && !direct) { MUSTAFAR_TRACE_END(); return; }
+            n_lo = 1;
+            n_hi = N;
+        }
+#pragma unroll 1
+        for (int c = 0; c < nck; c++) {
+            const uint32_t rows = (all >> (8 * c)) & 0xffu;
+            if (rows != 0u || direct) run_chunk(slab0 + c, rows, n_lo, n_hi);
+        }
+    } else {
+        run_chunk(slab0, 1u, 0, 1);
     }
     MUSTAFAR_TRACE_END();
 }
@@ -4131,6 +4268,7 @@ inline int value_split()
 // template flag WIN, CoefStride; 21 scalar spills, no private segment.  The call stays 26-27 us at c3: ~22 us of kernel + the combine launch.)
 // MUSTAFAR_VALUE_LEAN = 0 | 1 / mustafar_tune(7, .) force one form; unset (2): by size.
 int g_value_lean = -1;
+int g_value_lean8 = 1;   // round 6: the lean form also for the hook's 8 padded rows (mustafar_tune(13, 0): round 1's kernel for N = 8, as rounds 1-5)
 inline int value_lean_mode()
 {
     if (g_value_lean < 0) {
@@ -4140,7 +4278,7 @@ inline int value_lean_mode()
     return fma_engine() == 1 ? 0 : g_value_lean;
 }
 inline bool value_lean() { return value_lean_mode() == 1; }   // (forced on: the workgroup shape follows it, value_tb_stride)
-inline bool value_lean_for(int N, int64_t wg_blocks) { const int m = value_lean_mode(); return m == 1 || (m == 2 && N == 1 && wg_blocks < 24000); }
+inline bool value_lean_for(int N, int64_t wg_blocks) { const int m = value_lean_mode(); return m == 1 || (m == 2 && (N == 1 || g_value_lean8) && wg_blocks < 24000); }
 inline int value_tb_stride() { return value_lean() ? kWaves / 2 : value_split() == 2 ? kValueWaves / 2 : kWaves; }   // token blocks in flight per workgroup
 
 // One place that picks the value kernel instantiation.
@@ -4157,6 +4295,9 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
         if (window_rows_last(1)) wa.rows = -wa.rows;
     }
     if ((N == 1 || N == 8) && value_lean_for(N, (int64_t)(grid.y - (wa.rows < 0 ? -wa.rows : wa.rows)) * (T / 64))) {
+#ifndef MUSTAFAR_PROBE_NOPADWG   // (timing probe: no pad workgroups at all -- the slabs' row masks stay unwritten)
+        if (N > 1) grid.y += (grid.y * ((grid.x + MUSTAFAR_PAD_GROUP - 1) / MUSTAFAR_PAD_GROUP) + grid.x - 1) / grid.x;
+#endif   // (the pad workgroups behind the row-0 workgroups, one per head group and four chunks: value_lean_kernel)
 #define MUSTAFAR_LVL(GG)                                                                                                         \
     do {                                                                                                                         \
         if (N == 1 && wa.rows != 0)                                                                                                              \
@@ -4164,6 +4305,8 @@ void launch_value(hipStream_t st, dim3 grid, const uint64_t* bmp, const unsigned
                                   flags, T, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride);                    \
         else if (N == 1) hipExtLaunchKernelGGL((value_lean_kernel<GG, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,  \
                                           flags, T, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride);            \
+        else if (MUSTAFAR_PROBE_N1AS8) hipExtLaunchKernelGGL((value_lean_kernel<GG, 1>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,  \
+                                          flags, T, groups, Batch_Size, tb_per_wg, direct, 8 * ldb, wa, bmp_stride, idx_stride, nz_stride);        \
         else        hipExtLaunchKernelGGL((value_lean_kernel<GG, 8>), grid, dim3(kThreads), 0, st, ev0, ev1, 0, bmp, nz, idx, nz_off, p, out, ws,  \
                                           flags, T, groups, Batch_Size, tb_per_wg, direct, ldb, wa, bmp_stride, idx_stride, nz_stride);            \
     } while (0)
@@ -4280,7 +4423,7 @@ int Value_SplitK_API(void* stream, const void* /*A*/, const uint64_t* bmp, const
     launch_value(st, dim3(S, gy), bmp, nz, idx, NZ_offset, p, o, ws, flags, T, N, groups, Batch_Size, tb_per_wg, direct, T);
     int err = (int)hipGetLastError();
     if (err || direct) return err;
-    value_combine_kernel<<<(unsigned)(Batch_Size * N), 256, 0, st>>>(ws, flags, o, Batch_Size, N, S, groups, G);
+    value_combine_kernel<<<(unsigned)Batch_Size, 256, 0, st>>>(ws, flags, o, Batch_Size, N, S, groups, G);
     return (int)hipGetLastError();
 }
 
@@ -4751,6 +4894,7 @@ int mustafar_tune(int knob, int value)
         case 9: g_late_prio = value ? 1 : 0; return 0;
         case 10: g_finish1 = value ? 1 : 0; return 0;
         case 12: g_spec_k_bytes = value < 0 ? 0 : value; return 0;
+        case 13: g_value_lean8 = value ? 1 : 0; return 0;   // (round 6: 1 = the value entry point's 8-row calls on the lean form with pad workgroups behind the row-0 workgroups, 0 = round 1's kernel)
         case 11: g_small = value < 0 ? 0 : value > 2 ? 2 : value; return 0;   // (round 6: 0 = never the small-launch kernel, 1 = below one wave per SIMD, 2 = for every launch of two blocks per workgroup)
         default: return MUSTAFAR_EINVAL;
     }

@@ -146,6 +146,34 @@ def test_value_spmv_nonzero_pad_rows(pkg, groups, split):
     _check_spmv(out, C16, Cd, sumabs, "value-8rows")
 
 
+@pytest.mark.parametrize("groups,t,split", [(4, 1408, 11), (4, 1408, 6), (2, 704, 11), (1, 1408, 22)])
+def test_value_spmv_pad_rows_live_in_single_chunks(pkg, groups, t, split):
+    """Round 6: the lean form reads the pad rows in workgroups of their own, one per head group and FOUR token chunks, a byte of row mask per
+    chunk.  Pad rows that hold a non-zero in exactly one chunk -- the first, one in the middle of a group, the last column of the last (partial)
+    group -- and one head group with nothing: every slab's mask is its own, and the rows come out as the reference computes them."""
+    mp, _ = pkg
+    B = 2
+    c = make_cache("value", B, t, 128, 0.7, seed=123)
+    BH = B * groups
+    rng = np.random.default_rng(10)
+    p = np.zeros((BH, 8, t), np.float16)
+    p[:, 0] = (rng.random((BH, t)) / t).astype(np.float16)
+    p[0, 1, 5] = 0.25                       # first chunk only
+    p[0, 2, 130:140] = 0.125                # a chunk in the middle of the first group
+    p[BH - 1, 5, t - 1] = 0.5               # the last column: last chunk of the last group
+    p[groups - 1, 6] = (rng.random(t) / t).astype(np.float16)   # a whole row, last head of the first head group
+    p[0, 7, 64 * 9] = -0.0                  # minus zero is zero
+    bmp, nz, idx, off = _cache_to_dev(c)
+    ws = torch.zeros(1, dtype=torch.float16, device=DEV)
+    out = mp.mustafar_value_formulation(bmp, nz, idx, off, _t(p), ws, 128, t, BH, groups, split_k=split)
+    C16, Cd = orc.value_spmv(c["bmp"], np.concatenate(c["nzs"]), c["idx"], c["nz_offset"], p, 128, t, BH, groups)
+    V = c["pruned"].astype(np.float64)
+    sumabs = np.stack([np.abs(p[b].astype(np.float64)) @ np.abs(V[b // groups]) for b in range(BH)])
+    _check_spmv(out, C16, Cd, sumabs, "value-8rows-single-chunks")
+    assert not out[:, 3:5].any() and not out[:, 7].any(), "rows without a non-zero are exact zeros"
+    assert out[0, 1].any() and out[0, 2].any() and out[BH - 1, 5].any() and out[groups - 1, 6].any()
+
+
 def test_spmv_on_golden_compressed_streams(pkg, golden_dir):
     """Feed the REFERENCE-produced compressed tensors (Triton kernels, fixtures) straight to the HIP kernels."""
     mp, _ = pkg

@@ -348,3 +348,14 @@ def test_checker_tracks_divergent_regions_by_the_saved_mask():
     assert not run(nested + asm), "both regions are closed by the outer restore"
     assert len(run("\ts_and_saveexec_b64 s[8:9], vcc\n" + asm + "\n\ts_or_b64 exec, exec, s[8:9]")) == 1, "an asm statement inside an open region is reported"
     assert not run("\ts_and_saveexec_b64 s[8:9], vcc\n\tv_mov_b32_e32 v2, 0\n\ts_or_b64 exec, exec, s[8:9]\n" + asm)
+    # a ROTATED loop (round 6): the exit label -- and with it the restore -- stands ABOVE the back edge that sheds the lanes; nothing below it is inside
+    rotated = (".LBB0_4:\n\ts_or_b64 exec, exec, s[0:1]\n\ts_branch .LBB0_9\n.LBB0_5:\n\tv_mov_b32_e32 v2, 0\n\ts_andn2_b64 exec, exec, s[2:3]\n"
+               "\ts_cbranch_execz .LBB0_4\n\ts_branch .LBB0_5\n.LBB0_9:\n")
+    assert not run(rotated + asm), "the loop's lanes come back at the label above"
+    rotated2 = (".LBB0_4:\n\ts_or_b64 exec, exec, s[0:1]\n\ts_branch .LBB0_9\n.LBB0_5:\n\tv_mov_b32_e32 v2, 0\n\ts_andn2_b64 exec, exec, s[2:3]\n"
+                "\ts_cbranch_execnz .LBB0_5\n\ts_branch .LBB0_4\n.LBB0_9:\n")
+    assert not run(rotated2 + asm), "the same loop written as `continue while lanes remain`, then a branch up to the restore"
+    # ... and the last `if` of such a loop body: saved below, restored at the loop's head above; its region is the block that follows, up to the next label
+    tail_if = ".LBB0_4:\n\ts_or_b64 exec, exec, s[8:9]\n\tv_mov_b32_e32 v2, 0\n\ts_and_saveexec_b64 s[8:9], vcc\n\ts_cbranch_execz .LBB0_4\n"
+    assert len(run(tail_if + asm + "\n\ts_branch .LBB0_4\n.LBB0_9:\n")) == 1, "inside the block behind the save"
+    assert not run(tail_if + "\tv_mov_b32_e32 v3, 0\n\ts_branch .LBB0_4\n.LBB0_9:\n" + asm), "behind the next label the region is over"

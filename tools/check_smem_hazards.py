@@ -196,8 +196,16 @@ def check(asm_text):
         # ---- (2) EXEC discipline, (3) sink register: text order
         in_asm = exec_masked = False
         divergent, saved = 0, []
+        until_label = set()   # saved masks whose restore stands at a label ABOVE (a rotated loop): the region is the block that follows, up to the next label
+        label_at = {code.split(":")[0]: k for k, (_, code, _) in enumerate(ins) if code.startswith(".LBB")}
+        def exits_backward(k):   # behind ins[k]: `s_cbranch_execz <a label already passed>`, or `s_cbranch_execnz <loop>` + `s_branch <a label already passed>`
+            nxt = [ins[j][1].split() for j in range(k + 1, min(k + 3, len(ins)))]
+            back = lambda w, op: len(w) == 2 and w[0] == op and label_at.get(w[1], len(ins)) < k
+            if nxt and back(nxt[0], "s_cbranch_execz"):
+                return True
+            return len(nxt) == 2 and back(nxt[0], "s_cbranch_execnz") and back(nxt[1], "s_branch")
         sink_regs, sink_lines, vwrites, sink_end = set(), set(), [], None
-        for ln, code, _ in ins:
+        for k, (ln, code, _) in enumerate(ins):
             if code == "#SINKEND":
                 sink_end = ln
                 continue
@@ -210,6 +218,10 @@ def check(asm_text):
                 in_asm = exec_masked = False
                 continue
             if code.startswith(".LBB"):
+                if until_label:
+                    saved = [r for r in saved if r not in until_label]
+                    until_label.clear()
+                    divergent = len(saved)
                 continue
             parts = code.replace(",", " ").split()
             op, args = parts[0], parts[1:]
@@ -230,9 +242,12 @@ def check(asm_text):
                     sinks += 1
             elif "saveexec" in op and args:
                 saved.append(args[0])          # (the register pair that holds the mask to come back to)
+                if exits_backward(k):          # (round 6: the restore stands at a label above -- the last `if` of a rotated loop body)
+                    until_label.add(args[0])
                 divergent = len(saved)
             elif op == "s_andn2_b64" and args[:2] == ["exec", "exec"] and len(args) > 2 and args[2] not in saved:
-                saved.append(args[2])          # (a divergent loop sheds lanes; `s_or_b64 exec, exec, <the same pair>` brings them back)
+                if not exits_backward(k):      # (a loop whose exit label stands above restores there: nothing below this back edge is inside it)
+                    saved.append(args[2])      # (a divergent loop sheds lanes; `s_or_b64 exec, exec, <the same pair>` brings them back)
                 divergent = len(saved)
             elif op == "s_or_b64" and args[:2] == ["exec", "exec"] and saved:
                 # restoring a mask closes its region AND every region opened inside it (round 6: an inner `if` at the very end of an outer one is

@@ -67,9 +67,15 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rows", nargs="+", type=int, default=[1, 8])
     ap.add_argument("--adversarial", action="store_true", help="all kept values in one 64-channel half (empty + dense tiles)")
+    ap.add_argument("--tune", nargs="*", default=[], help="mustafar_tune knobs, knob=value (e.g. 13=0: 8-row value calls on round 1's kernel)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev).manual_seed(42)
+    if a.tune:
+        from mustafar_amd import _lib
+        for kv in a.tune:
+            k, v = kv.split("=")
+            assert _lib.load().mustafar_tune(int(k), int(v)) == 0
     for name in a.cfg:
         Hq, Hkv, s, L, batch = CFG[name]
         T = ((L - 32) // 256) * 256
@@ -87,7 +93,7 @@ def main():
             tv = timeit(lambda: mp.mustafar_value_formulation(*vc, p, ws, 128, T, BH, groups), a.iters)
             bk = meta + 2 * kc[1].numel() + BH * 128 * 2 + BH * T * 2
             bv = meta + 2 * vc[1].numel() + BH * T * 2 + BH * 128 * 2
-            print(json.dumps(dict(cfg=name + ("-adversarial" if a.adversarial else ""), rows=N, T=T, Bp=Bp, BH=BH, key_us=round(tk * 1e6, 2), value_us=round(tv * 1e6, 2),
+            print(json.dumps(dict(cfg=name + ("-adversarial" if a.adversarial else "") + ("".join(" tune " + t for t in a.tune)), rows=N, T=T, Bp=Bp, BH=BH, key_us=round(tk * 1e6, 2), value_us=round(tv * 1e6, 2),
                                   key_alg_MB=round(bk / 1e6, 2), value_alg_MB=round(bv / 1e6, 2),
                                   key_GBps=round(bk / tk / 1e9, 1), value_GBps=round(bv / tv / 1e9, 1))), flush=True)
         del kc, vc
