@@ -4277,8 +4277,11 @@ inline int value_lean_mode()
     }
     return fma_engine() == 1 ? 0 : g_value_lean;
 }
-inline bool value_lean() { return value_lean_mode() == 1; }   // (forced on: the workgroup shape follows it, value_tb_stride)
-inline bool value_lean_for(int N, int64_t wg_blocks) { const int m = value_lean_mode(); return m == 1 || (m == 2 && (N == 1 || g_value_lean8) && wg_blocks < 24000); }
+// Round 6: with the probabilities prefetched (MUSTAFAR_VL_PFCOEF) the lean form wins at every size -- c5 (32 k workgroup-blocks), us per call, lean / round 1's kernel:
+// one row 83.4 / 92.5, eight rows 83.6 / 95.9 (round 5, without the prefetch: 80.6 / 78.6, and the size limit of 24 k workgroup-blocks that came from it) -- so "by size"
+// (mode 2, the default) now means: lean whenever the vector engines run, for N = 1 and -- mustafar_tune(13, .) -- the hook's 8 padded rows.
+inline bool value_lean() { return value_lean_mode() != 0; }   // (the workgroup shape follows it, value_tb_stride)
+inline bool value_lean_for(int N, int64_t /*wg_blocks*/) { const int m = value_lean_mode(); return m == 1 || (m == 2 && (N == 1 || g_value_lean8)); }
 inline int value_tb_stride() { return value_lean() ? kWaves / 2 : value_split() == 2 ? kValueWaves / 2 : kWaves; }   // token blocks in flight per workgroup
 
 // One place that picks the value kernel instantiation.
