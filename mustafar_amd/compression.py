@@ -57,7 +57,7 @@ class StreamPiece(torch.Tensor):
             tensors = args[0]
             dim = kwargs.get("dim", args[1] if len(args) > 1 else 0)
             n = len(tensors)
-            if dim == 0 and n and all(type(t) is StreamPiece for t in tensors):
+            if dim == 0 and n and all(type(t) is StreamPiece and hasattr(t, "_bk") for t in tensors):   # (a piece made by anything but `pieces_of` / `wrap` knows no buffer: plain cat)
                 bk = tensors[0]._bk
                 if n == len(bk.indices) and [t._ix for t in tensors] == bk.indices and all(t._bk is bk for t in tensors):
                     return bk.buf                                       # every piece of one buffer, in order: the buffer
@@ -105,13 +105,28 @@ def pieces_of(flat: torch.Tensor, offs: List[int]) -> List[torch.Tensor]:
         views = [flat[offs[b]:offs[b + 1]] for b in range(n)]
     else:
         views = list(torch.unsafe_split_with_sizes(flat, [offs[b + 1] - offs[b] for b in range(n)]))
+    retype = _RETYPE_IN_PLACE
     for b, p in enumerate(views):
-        if type(p) is torch.Tensor:
+        if retype and type(p) is torch.Tensor:
             p.__class__ = StreamPiece
-        else:                                   # `flat` itself a subclass: leave its type system alone
+        else:                                   # `flat` itself a subclass (leave its type system alone), or a PyTorch whose tensor objects cannot be re-typed
             p = views[b] = torch.Tensor._make_subclass(StreamPiece, p)
         p._bk, p._ix = bk, b
     return views
+
+
+def _can_retype_in_place() -> bool:
+    """Whether this PyTorch lets a plain tensor OBJECT become a `StreamPiece` by `__class__` assignment (CPython allows it between heap types of one
+    layout; true for every PyTorch 2.x tried).  Probed once at import, on a CPU scalar: where it is refused, `pieces_of` wraps every view instead."""
+    try:
+        t = torch.empty(0)
+        t.__class__ = StreamPiece
+        return type(t) is StreamPiece and (t + 1).numel() == 0
+    except Exception:
+        return False
+
+
+_RETYPE_IN_PLACE = _can_retype_in_place()
 
 
 def _stream_ptr(device: torch.device) -> int:
