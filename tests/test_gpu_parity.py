@@ -307,6 +307,40 @@ def test_conversion_form_by_size_and_the_mirror_reused_across_calls():
     assert comp.convert_fallbacks == 0
 
 
+def test_conversions_from_two_host_threads_on_their_own_streams():
+    """The polled mirror of the stream offsets is per host THREAD (and device, head count): two threads converting different inputs on streams of their
+    own, twenty times each, get what a single thread gets -- neither sees the other's sentinel or sizes."""
+    import threading
+    from mustafar_amd import compression as comp
+    xs = [torch.from_numpy(make_cache("key", 6, 320, 128, 0.7, 31)["pruned"]).to(DEV), torch.from_numpy(make_cache("value", 6, 448, 128, 0.6, 32)["pruned"]).to(DEV)]
+    fns = [comp.convert_key_batched, comp.convert_value_batched]
+    want = [[t.clone() if torch.is_tensor(t) else torch.cat(t).clone() for t in fn(x)] for fn, x in zip(fns, xs)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(st):
+                for _ in range(20):
+                    bmp, acc, nz = fns[i](xs[i])
+                    got = [bmp, acc, torch.cat(nz)]
+                    st.synchronize()
+                    for g, w in zip(got, want[i]):
+                        if not torch.equal(g.view(torch.int16) if g.dtype == torch.float16 else g, w.view(torch.int16) if w.dtype == torch.float16 else w):
+                            errors.append(f"thread {i}: mismatch")
+                            return
+        except Exception as e:   # noqa: BLE001 -- reported below, in the main thread
+            errors.append(f"thread {i}: {e!r}")
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 def test_empty_and_dense_blocks(pkg):
     """All-zero input (every tile empty, zero-length streams) and fully dense input (nnz = 64 everywhere)."""
     mp, comp = pkg
