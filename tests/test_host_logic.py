@@ -359,3 +359,43 @@ def test_checker_tracks_divergent_regions_by_the_saved_mask():
     tail_if = ".LBB0_4:\n\ts_or_b64 exec, exec, s[8:9]\n\tv_mov_b32_e32 v2, 0\n\ts_and_saveexec_b64 s[8:9], vcc\n\ts_cbranch_execz .LBB0_4\n"
     assert len(run(tail_if + asm + "\n\ts_branch .LBB0_4\n.LBB0_9:\n")) == 1, "inside the block behind the save"
     assert not run(tail_if + "\tv_mov_b32_e32 v3, 0\n\ts_branch .LBB0_4\n.LBB0_9:\n" + asm), "behind the next label the region is over"
+
+
+def test_the_polled_mirror_of_the_stream_offsets_waits_and_gives_up_correctly():
+    """compression._await_offsets (round 6; no GPU: a numpy array stands for the pinned mirror, an object with query() for the stream): returns once no
+    entry is the negative sentinel, whatever order the entries arrive in; a stream that has drained while entries are still negative is an error, not a wait."""
+    import threading
+    import time
+    from mustafar_amd import compression as comp
+
+    class Stream:
+        def __init__(self, done):
+            self.done, self.queries = done, 0
+
+        def query(self):
+            self.queries += 1
+            return self.done
+
+    arr = np.full(9, -1, np.int64)
+    want = [0, 8, 8, 24, 40, 40, 64, 72, 96]
+
+    def device():   # the entries land one by one, back to front
+        for i in reversed(range(9)):
+            time.sleep(0.002)
+            arr[i] = want[i]
+
+    t = threading.Thread(target=device)
+    t.start()
+    got = comp._await_offsets(arr, Stream(False))
+    t.join()
+    assert got == want
+    # nothing ever arrives and the stream reports itself drained: raise instead of spinning for ever
+    arr[:] = -1
+    st = Stream(True)
+    with pytest.raises(RuntimeError, match="no stream offsets"):
+        comp._await_offsets(arr, st)
+    assert st.queries >= 1
+    # everything already there: no query at all
+    arr[:] = want
+    st = Stream(False)
+    assert comp._await_offsets(arr, st) == want and st.queries == 0
