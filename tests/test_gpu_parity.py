@@ -174,6 +174,40 @@ def test_value_spmv_pad_rows_live_in_single_chunks(pkg, groups, t, split):
     assert out[0, 1].any() and out[0, 2].any() and out[BH - 1, 5].any() and out[groups - 1, 6].any()
 
 
+def test_value_spmv_eight_rows_replayed_from_a_graph_follows_the_pad_rows(pkg):
+    """The 8-row value call captured ONCE (the workspace is the call's own allocation inside the capture) and replayed over operands that change in place: pad rows all zero,
+    then a pad row live in one token chunk, then zero again.  Which rows a launch computes is decided on the device at every replay (the pad workgroups' masks), not
+    at capture time."""
+    mp, _ = pkg
+    groups, B, t = 4, 2, 1024
+    c = make_cache("value", B, t, 128, 0.7, seed=77)
+    BH = B * groups
+    rng = np.random.default_rng(12)
+    p0 = np.zeros((BH, 8, t), np.float16)
+    p0[:, 0] = (rng.random((BH, t)) / t).astype(np.float16)
+    p1 = p0.copy()
+    p1[3, 5, 700:720] = 0.25
+    p1[:, 0] = (rng.random((BH, t)) / t).astype(np.float16)
+    bmp, nz, idx, off = _cache_to_dev(c)
+    ws = torch.zeros(1, dtype=torch.float16, device=DEV)
+    p_dev = _t(p0)
+    mp.mustafar_value_formulation(bmp, nz, idx, off, p_dev, ws, 128, t, BH, groups)   # (warm-up outside the capture)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = mp.mustafar_value_formulation(bmp, nz, idx, off, p_dev, ws, 128, t, BH, groups)
+    V = c["pruned"].astype(np.float64)
+    for p in (p0, p1, p0):
+        p_dev.copy_(_t(p))
+        g.replay()
+        torch.cuda.synchronize()
+        C16, Cd = orc.value_spmv(c["bmp"], np.concatenate(c["nzs"]), c["idx"], c["nz_offset"], p, 128, t, BH, groups)
+        sumabs = np.stack([np.abs(p[b].astype(np.float64)) @ np.abs(V[b // groups]) for b in range(BH)])
+        _check_spmv(out, C16, Cd, sumabs, "value-8rows-graph")
+        live = np.abs(p[:, 1:]).sum(-1) > 0
+        assert np.array_equal(out[:, 1:].abs().sum(-1).cpu().numpy() > 0, live), "exactly the pad rows that hold a non-zero come out non-zero"
+
+
 def test_spmv_on_golden_compressed_streams(pkg, golden_dir):
     """Feed the REFERENCE-produced compressed tensors (Triton kernels, fixtures) straight to the HIP kernels."""
     mp, _ = pkg

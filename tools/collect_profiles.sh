@@ -57,6 +57,7 @@ python3 tools/mem_spd.py --api fused reference > $O/mem_spd.txt 2> $O/mem_spd.er
 python3 tools/bench_compress.py c3 c4 2> $O/compress.err | grep cfg > $O/compress.txt
 python3 tools/probes/convert_breakdown.py c1 c2 c3 c4 c5 2> $O/convert_breakdown.err | grep cfg > $O/convert_breakdown.txt; nonempty $O/convert_breakdown.txt
 tools/probes/prof_value8.sh > $O/value8_kernels.txt 2> $O/value8_kernels.err; nonempty $O/value8_kernels.txt
+hipcc --offload-arch=gfx950 -O2 -o tools/ubench/inlaunch_merge tools/ubench/inlaunch_merge.hip 2> $O/inlaunch_merge.err && timeout -k 10 120 ./tools/ubench/inlaunch_merge > $O/inlaunch_merge.txt 2>> $O/inlaunch_merge.err; nonempty $O/inlaunch_merge.txt
 python3 tools/bench_append.py 2> $O/append.err | grep cfg > $O/append.txt
 MUSTAFAR_FMA_ENGINE=valu python3 tools/microbench.py --cfg c3 c2 c3 c4 c5 --rows 1 8 --iters 30 2> $O/microbench.err | grep cfg > $O/microbench_valu.txt
 MUSTAFAR_FMA_ENGINE=mfma python3 tools/microbench.py --cfg c3 c3 c4 c5 --rows 1 --iters 30 2>> $O/microbench.err | grep cfg > $O/microbench_mfma.txt
